@@ -1,0 +1,109 @@
+/*
+ * nblic_amd.h -- C ABI of libnblic_amd.so, the MI355X-native drop-in for the NBLIC v0.3
+ * codec entry points.  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Section 1 re-declares the reference's own API with identical names, argument meaning and
+ * return conventions, so a caller of the reference library (its only caller is main(),
+ * src/NBLIC_main.c:184-188,223-226) links against this library unchanged.
+ * Section 2 is additive: a context + batch interface that keeps several images in flight per
+ * GPU (the reference has no equivalent; it is what bench.py and the Python host layer use).
+ *
+ * The compute path is HIP only.  If no gfx950 device is usable every entry point that has to
+ * compute returns -1 after printing a diagnostic to stderr -- there is no CPU fallback.
+ */
+#ifndef NBLIC_AMD_H
+#define NBLIC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* limits, same values as the reference (src/NBLIC.h:29-31, src/QNBLIC.h:9-11) */
+#define NBLIC_MAX_HEIGHT     65535
+#define NBLIC_MAX_WIDTH      65535
+#define NBLIC_MAX_IMG_SIZE   100000000
+#define QNBLIC_MAX_HEIGHT    65535
+#define QNBLIC_MAX_WIDTH     65535
+#define QNBLIC_MAX_IMG_SIZE  100000000
+
+/* ---- 1. drop-in entry points -------------------------------------------------------- */
+
+/* Replaces NBLICcompress (src/NBLIC.h:54, src/NBLIC.c:915).
+ * verbose  : accepted, ignored on the GPU path (the reference prints row progress).
+ * p_buf    : caller-owned output, no capacity argument (reference contract); worst case seen
+ *            is ~1.0025 B/px + 20, the reference CLI provides 2 B/px.
+ * p_img    : 8-bit gray, row-major, stride == width.  WRITTEN: receives the reconstruction
+ *            (identical bytes when *p_near == 0), as the reference does at NBLIC.c:876.
+ * p_near   : clamped to [0,9] and written back.   p_effort : clamped to [1,3], written back.
+ * returns  : stream length in BYTES, or -1.                                              */
+int NBLICcompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int height, int width,
+                  int *p_near, int *p_effort);
+
+/* Replaces NBLICdecompress (src/NBLIC.h:72, src/NBLIC.c:924).  All four int outputs are
+ * parsed from the 16-byte header.  returns 0 or -1.                                       */
+int NBLICdecompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int *p_height, int *p_width,
+                    int *p_near, int *p_effort);
+
+/* Replace QNBLICcompress / QNBLICdecompress / QNBLICcompressMultiThread (src/QNBLIC.h:14-18,
+ * src/QNBLIC.c:562,493,872).  Effort 0, lossless only.  compress returns the length in
+ * 16-bit WORDS (the reference's caller doubles it, NBLIC_main.c:184-186) or -1.           */
+int QNBLICcompress(uint16_t *p_buf, unsigned char *p_img, int height, int width);
+int QNBLICdecompress(uint16_t *p_buf, unsigned char *p_img, int *p_height, int *p_width);
+int QNBLICcompressMultiThread(uint16_t *p_buf, unsigned char *p_img, int height, int width);
+
+/* ---- 2. additive context / batch API ------------------------------------------------- */
+
+typedef struct nblic_amd_ctx nblic_amd_ctx;
+
+/* device   : HIP device ordinal.
+ * n_slots  : images kept in flight on the GPU (each owns a stream and a workspace); >= 1.
+ * n_coders : host threads running the serial range-coder stage; >= 1.
+ * returns NULL (and prints why) when the device cannot be used.                            */
+nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders);
+void nblic_amd_destroy(nblic_amd_ctx *ctx);
+
+/* Encode n_images gray planes at -n0 -e1 (lossless) into byte-exact .nblic streams.
+ * imgs[k]        : plane k, heights[k] x widths[k], stride == width.
+ * imgs_on_device : 0 = host pointers, 1 = device (HBM) pointers on the context's device.
+ * outs[k]        : host buffer for stream k, out_caps[k] bytes (checked; -1 if too small).
+ * out_lens[k]    : receives the stream length in bytes, or -1 for that image.
+ * returns 0 when every image succeeded, -1 otherwise.                                      */
+int nblic_amd_encode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned char *const *imgs, int imgs_on_device,
+                           const int *heights, const int *widths, unsigned char *const *outs,
+                           const size_t *out_caps, long *out_lens);
+
+/* Opt-in: raise the pixel-count limit above NBLIC_MAX_IMG_SIZE for this context (config 5 of
+ * BASELINE.json exceeds the reference's own limit).  0 restores the reference limit.       */
+void nblic_amd_set_max_pixels(nblic_amd_ctx *ctx, long max_pixels);
+
+/* Per-stage device times of the LAST nblic_amd_encode_batch, measured with HIP events on the
+ * streams the kernels ran on and summed over the batch's images.  Writes up to `cap` entries
+ * of milliseconds into ms[] and matching static strings into names[]; returns the count.
+ * Timing is recorded only after nblic_amd_enable_timing(ctx, 1).                           */
+void nblic_amd_enable_timing(nblic_amd_ctx *ctx, int on);
+int nblic_amd_stage_times(nblic_amd_ctx *ctx, double *ms, const char **names, int cap);
+
+/* Bins coded / host range-coder seconds summed over the last batch (for reporting). */
+void nblic_amd_last_stats(nblic_amd_ctx *ctx, double *total_bins, double *coder_seconds_sum);
+
+/* Stage-level debug hook used by the parity tests: runs the staged -e1 pipeline on ONE host
+ * image and copies the named intermediate array back.  which: 0 rec1(u32) 1 pxs(u16) 2 z(u8)
+ * 3 cnt(u8) 4 events(u32) 5 coded(u16).  Returns the element count, or -1.                 */
+long nblic_amd_debug_stage(nblic_amd_ctx *ctx, const unsigned char *img, int height, int width, int which,
+                           void *out, size_t out_bytes);
+
+/* The host half of the path on its own: the serial range-coder stage (src/NBLIC.c:552-586) over
+ * n coded bins (u16 each: probability of a 1 in 1/4096 in bits 0-11, the bin in bit 15).
+ * Writes at most cap bytes (coder bytes + 4 flush bytes, no header); returns the byte count or
+ * (size_t)-1 when cap is too small.  Needs no GPU.                                         */
+size_t nblic_amd_range_code(const uint16_t *coded, size_t n, unsigned char *out, size_t cap);
+
+const char *nblic_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBLIC_AMD_H */

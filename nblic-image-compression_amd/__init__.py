@@ -1,0 +1,228 @@
+"""nblic-image-compression_amd -- MI355X-native NBLIC v0.3 hot path (host-side Python layer).
+
+The product is ``libnblic_amd.so`` (hand-written HIP kernels for gfx950 + a thin C++ host
+pipeline), whose C ABI is declared in ``include/nblic_amd.h``.  This module is only the
+binding that tests, ``bench.py`` and Python callers use; it mirrors the reference's
+operator interface for the path (``NBLICcompress`` / ``NBLICdecompress``: same argument
+meaning, same clamping and error conventions, reference: src/NBLIC.h:54,72) and adds the
+batch interface.  There is no CPU fallback: if the library is missing or no HIP device is
+usable, calls raise.
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("nblic-image-compression_amd")``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnblic_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "nblic_amd.h")
+
+_u8p = C.POINTER(C.c_uint8)
+_lib = None
+
+# every symbol include/nblic_amd.h declares
+EXPORTS = (
+    "NBLICcompress", "NBLICdecompress", "QNBLICcompress", "QNBLICdecompress", "QNBLICcompressMultiThread",
+    "nblic_amd_create", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_set_max_pixels",
+    "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_stats", "nblic_amd_debug_stage",
+    "nblic_amd_range_code", "nblic_amd_version",
+)
+
+
+def build(force: bool = False) -> str:
+    """Compile libnblic_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [INCLUDE]
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        r = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building libnblic_amd.so failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """dlopen the HIP library.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950). "
+                           "There is no CPU fallback for the NBLIC hot path.")
+    lib = C.CDLL(LIB_PATH)
+    ip = C.POINTER(C.c_int)
+    lib.NBLICcompress.restype = C.c_int
+    lib.NBLICcompress.argtypes = [C.c_int, _u8p, _u8p, C.c_int, C.c_int, ip, ip]
+    lib.NBLICdecompress.restype = C.c_int
+    lib.NBLICdecompress.argtypes = [C.c_int, _u8p, _u8p, ip, ip, ip, ip]
+    u16p = C.POINTER(C.c_uint16)
+    lib.QNBLICcompress.restype = C.c_int
+    lib.QNBLICcompress.argtypes = [u16p, _u8p, C.c_int, C.c_int]
+    lib.QNBLICcompressMultiThread.restype = C.c_int
+    lib.QNBLICcompressMultiThread.argtypes = [u16p, _u8p, C.c_int, C.c_int]
+    lib.QNBLICdecompress.restype = C.c_int
+    lib.QNBLICdecompress.argtypes = [u16p, _u8p, ip, ip]
+    lib.nblic_amd_create.restype = C.c_void_p
+    lib.nblic_amd_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.nblic_amd_destroy.restype = None
+    lib.nblic_amd_destroy.argtypes = [C.c_void_p]
+    lib.nblic_amd_encode_batch.restype = C.c_int
+    lib.nblic_amd_encode_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, ip, ip,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
+    lib.nblic_amd_set_max_pixels.restype = None
+    lib.nblic_amd_set_max_pixels.argtypes = [C.c_void_p, C.c_long]
+    lib.nblic_amd_enable_timing.restype = None
+    lib.nblic_amd_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.nblic_amd_stage_times.restype = C.c_int
+    lib.nblic_amd_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.c_int]
+    lib.nblic_amd_last_stats.restype = None
+    lib.nblic_amd_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.nblic_amd_debug_stage.restype = C.c_long
+    lib.nblic_amd_debug_stage.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.nblic_amd_range_code.restype = C.c_size_t
+    lib.nblic_amd_range_code.argtypes = [C.POINTER(C.c_uint16), C.c_size_t, _u8p, C.c_size_t]
+    lib.nblic_amd_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def out_capacity(h: int, w: int) -> int:
+    """Output provision per image: the reference CLI's 2 B/px (NBLIC_main.c:141) plus slack."""
+    return 2 * h * w + 4096
+
+
+# ---------------------------------------------------------------------------------------------
+# drop-in operators (same meaning as the reference's NBLICcompress / NBLICdecompress)
+# ---------------------------------------------------------------------------------------------
+def compress(img: np.ndarray, near: int = 0, effort: int = 1) -> Tuple[Optional[bytes], np.ndarray, int, int]:
+    """``NBLICcompress``: returns (stream or None on -1, reconstruction, clamped near, clamped effort).
+
+    Like the reference the encoder overwrites its input plane with the reconstruction
+    (NBLIC.c:876); here the caller's array is left alone and the overwritten copy is returned.
+    """
+    lib = load_library()
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    rec = img.copy()
+    out = np.empty(out_capacity(h, w), np.uint8)
+    n, e = C.c_int(near), C.c_int(effort)
+    ln = lib.NBLICcompress(0, out.ctypes.data_as(_u8p), rec.ctypes.data_as(_u8p), h, w, C.byref(n), C.byref(e))
+    if ln < 0:
+        return None, rec, n.value, e.value
+    return out[:ln].tobytes(), rec, n.value, e.value
+
+
+def decompress(stream: bytes) -> Optional[Tuple[np.ndarray, int, int]]:
+    """``NBLICdecompress``: returns (image, near, effort) or None on -1."""
+    lib = load_library()
+    if len(stream) < 16:
+        return None
+    buf = np.frombuffer(bytes(stream), np.uint8).copy()
+    h = (int(buf[9]) << 8) | int(buf[10])
+    w = (int(buf[11]) << 8) | int(buf[12])
+    img = np.zeros((max(h, 1), max(w, 1)), np.uint8)
+    hh, ww, n, e = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib.NBLICdecompress(0, buf.ctypes.data_as(_u8p), img.ctypes.data_as(_u8p), C.byref(hh), C.byref(ww), C.byref(n), C.byref(e))
+    if rc != 0:
+        return None
+    return img[:hh.value, :ww.value], n.value, e.value
+
+
+def range_code(coded: np.ndarray, cap: Optional[int] = None) -> Optional[bytes]:
+    """Host range-coder stage alone (``nblic_amd_range_code``); needs no GPU."""
+    lib = load_library()
+    coded = np.ascontiguousarray(coded, np.uint16)
+    cap = coded.size * 4 + 16 if cap is None else cap
+    out = np.empty(max(cap, 1), np.uint8)
+    n = lib.nblic_amd_range_code(coded.ctypes.data_as(C.POINTER(C.c_uint16)), coded.size, out.ctypes.data_as(_u8p), cap)
+    if n == C.c_size_t(-1).value:
+        return None
+    return out[:n].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------
+# batch context
+# ---------------------------------------------------------------------------------------------
+class Context:
+    """Several images in flight on one GPU (``nblic_amd_create``)."""
+
+    def __init__(self, device: int = 0, n_slots: int = 4, n_coders: int = 4):
+        self.lib = load_library()
+        self.handle = self.lib.nblic_amd_create(device, n_slots, n_coders)
+        if not self.handle:
+            raise RuntimeError("nblic_amd_create failed: no usable HIP device (the hot path has no CPU fallback)")
+        self.device, self.n_slots, self.n_coders = device, n_slots, n_coders
+
+    def close(self):
+        if self.handle:
+            self.lib.nblic_amd_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enable_timing(self, on: bool = True):
+        self.lib.nblic_amd_enable_timing(self.handle, int(on))
+
+    def set_max_pixels(self, n: int):
+        self.lib.nblic_amd_set_max_pixels(self.handle, n)
+
+    def encode_ptrs(self, ptrs: Sequence[int], shapes: Sequence[Tuple[int, int]], on_device: bool,
+                    outs: Optional[List[np.ndarray]] = None) -> Tuple[List[np.ndarray], np.ndarray]:
+        """Encode planes given as raw addresses (host or device).  Returns (out buffers, lengths)."""
+        k = len(ptrs)
+        if outs is None:
+            outs = [np.empty(out_capacity(h, w), np.uint8) for (h, w) in shapes]
+        imgs = (C.c_void_p * k)(*[C.c_void_p(int(p)) for p in ptrs])
+        hs = (C.c_int * k)(*[int(s[0]) for s in shapes])
+        ws = (C.c_int * k)(*[int(s[1]) for s in shapes])
+        op = (C.c_void_p * k)(*[C.c_void_p(o.ctypes.data) for o in outs])
+        caps = (C.c_size_t * k)(*[o.size for o in outs])
+        lens = (C.c_long * k)()
+        rc = self.lib.nblic_amd_encode_batch(self.handle, k, imgs, int(on_device), hs, ws, op, caps, lens)
+        arr = np.array(list(lens), dtype=np.int64)
+        if rc != 0:
+            raise RuntimeError(f"nblic_amd_encode_batch failed (lengths {arr.tolist()})")
+        return outs, arr
+
+    def encode_batch(self, imgs: Sequence[np.ndarray]) -> List[bytes]:
+        """-n0 -e1 encode of host planes; returns the .nblic streams."""
+        planes = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        outs, lens = self.encode_ptrs([p.ctypes.data for p in planes], [p.shape for p in planes], False)
+        return [o[:int(n)].tobytes() for o, n in zip(outs, lens)]
+
+    def stage_times(self) -> dict:
+        ms = (C.c_double * 16)()
+        names = (C.c_char_p * 16)()
+        n = self.lib.nblic_amd_stage_times(self.handle, ms, names, 16)
+        return {names[i].decode(): ms[i] for i in range(n)}
+
+    def last_stats(self) -> Tuple[float, float]:
+        b, s = C.c_double(), C.c_double()
+        self.lib.nblic_amd_last_stats(self.handle, C.byref(b), C.byref(s))
+        return b.value, s.value
+
+    _STAGE = {"rec1": (0, np.uint32), "pxs": (1, np.uint16), "z": (2, np.uint8), "cnt": (3, np.uint8),
+              "events": (4, np.uint32), "coded": (5, np.uint16)}
+
+    def debug_stage(self, img: np.ndarray, name: str) -> np.ndarray:
+        """Intermediate array of the staged -e1 pipeline for one image (kernel parity tests)."""
+        which, dt = self._STAGE[name]
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.empty(40 * h * w + 64, dt)
+        cnt = self.lib.nblic_amd_debug_stage(self.handle, img.ctypes.data_as(_u8p), h, w, which,
+                                             C.c_void_p(out.ctypes.data), out.nbytes)
+        if cnt < 0:
+            raise RuntimeError("nblic_amd_debug_stage failed")
+        return out[:cnt].copy()

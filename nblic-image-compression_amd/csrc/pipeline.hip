@@ -1,0 +1,480 @@
+// pipeline.hip -- host side of libnblic_amd.so: workspaces, streams, the serial range-coder
+// stage (S6) on host threads, and the C ABI declared in include/nblic_amd.h.
+//
+// One `Slot` = one image in flight on the GPU: its own HIP stream, device workspace and a
+// pinned host buffer that receives the coded-bin stream (u16 per bin).  The submission thread
+// keeps every free slot busy; as soon as a slot's device->host copy lands, a coder thread
+// turns the bins into the byte-exact range-coder stream (NBLIC.c:552-586) while the GPU is
+// already working on the next images.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/nblic_amd.h"
+#include "kernels_e1.h"
+#include "model.h"
+#include "serial_engine.h"
+
+namespace nblic {
+
+#define HIP_OK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            fprintf(stderr, "[nblic_amd] %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return false;                                                                     \
+        }                                                                                     \
+    } while (0)
+
+// ---- S6: 32-bit carry-less binary range coder (NBLIC.c:527-586), encoder side ------------
+// coded[r] = prob (12 bit, P(bin==1)) | bin << 15.  Bin 1 takes the lower part of [lo, hi].
+// Returns the number of bytes written, or SIZE_MAX if `cap` bytes were not enough.
+size_t range_code(const uint16_t *coded, size_t n, uint8_t *out, size_t cap) {
+    uint32_t lo = 0, hi = 0xFFFFFFFFu;
+    uint8_t *p = out, *end = out + (cap < 4 ? 0 : cap - 4);          // keep room for the flush
+    if (cap < 4) return SIZE_MAX;
+    for (size_t r = 0; r < n; r++) {
+        uint32_t e = coded[r];
+        uint32_t cut = lo + uint32_t((uint64_t(hi - lo) * (e & 0xFFFu)) >> 12);
+        bool one = (e >> 15) != 0;
+        hi = one ? cut : hi;
+        lo = one ? lo : cut + 1;
+        while (((lo ^ hi) >> 24) == 0) {
+            if (p == end) return SIZE_MAX;
+            *p++ = uint8_t(hi >> 24);
+            lo <<= 8;
+            hi = (hi << 8) | 0xFFu;
+        }
+    }
+    for (int k = 0; k < 4; k++) { *p++ = uint8_t(lo >> 24); lo <<= 8; }
+    return size_t(p - out);
+}
+
+void write_header(uint8_t *p, int h, int w, int near, int k_step, int effort) {   // NBLIC.c:682-694
+    memcpy(p, "NBLIC0.3", 8);
+    p[8] = 1;
+    p[9] = uint8_t(h >> 8); p[10] = uint8_t(h);
+    p[11] = uint8_t(w >> 8); p[12] = uint8_t(w);
+    p[13] = uint8_t(near); p[14] = uint8_t(k_step); p[15] = uint8_t(effort);
+}
+
+bool size_ok(int h, int w, long max_px) {                                          // NBLIC.c:717-729
+    return h > 0 && w > 0 && h <= NBLIC_MAX_HEIGHT && w <= NBLIC_MAX_WIDTH && long(h) * long(w) <= max_px;
+}
+
+// ---- tiny thread pool ----------------------------------------------------------------------
+class Pool {
+  public:
+    explicit Pool(int n) {
+        for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void submit(std::function<void()> f) {
+        { std::lock_guard<std::mutex> g(m_); q_.push_back(std::move(f)); }
+        cv_.notify_one();
+    }
+  private:
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                f = std::move(q_.front()); q_.pop_front();
+            }
+            f();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::deque<std::function<void()>> q_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
+// ---- one image in flight -------------------------------------------------------------------
+struct Slot {
+    int id = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    E1Timers tm{};
+    E1Buffers b{};
+    size_t px_cap = 0, ev_cap = 0, img_cap = 0, h_cap = 0;
+    uint8_t *d_img = nullptr;         // device copy when the caller hands a host image
+    uint32_t *h_totals = nullptr;     // pinned, 4 words
+    uint16_t *h_coded = nullptr;      // pinned, h_cap entries
+    // current job
+    int job = -1, h = 0, w = 0;
+    uint32_t n_ev = 0;
+};
+
+template <class T> static bool dev_alloc(T *&p, size_t count) {
+    if (p) hipFree(p);
+    p = nullptr;
+    HIP_OK(hipMalloc((void **)&p, count * sizeof(T)));
+    return true;
+}
+
+}  // namespace nblic
+
+using namespace nblic;
+
+struct nblic_amd_ctx {
+    int device = 0;
+    long max_px = kMaxPixels;
+    bool timing = false;
+    std::vector<Slot> slots;
+    Pool *pool = nullptr;
+    std::mutex api;                       // one batch at a time per context
+    // free-slot list, fed by coder threads
+    std::mutex fm;
+    std::condition_variable fcv;
+    std::deque<int> free_slots;
+    int coding = 0;                       // S6 tasks outstanding
+    // reporting
+    double stage_ms[kE1Marks - 1] = {0};
+    double total_bins = 0, coder_s = 0;
+    SerialEngine serial;
+};
+
+namespace nblic {
+
+static bool slot_init(Slot &s, int id) {
+    s.id = id;
+    HIP_OK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    for (auto &e : s.tm.ev) HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipHostMalloc((void **)&s.h_totals, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_OK(hipMalloc((void **)&s.b.table, size_t(4096) * kMaxSegments * sizeof(uint32_t)));
+    HIP_OK(hipMalloc((void **)&s.b.scan_sums, size_t(1) << 20));
+    HIP_OK(hipMalloc((void **)&s.b.totals, 4 * sizeof(uint32_t)));
+    HIP_OK(hipMalloc((void **)&s.b.ctx_state, kContexts * sizeof(int)));
+    HIP_OK(hipMalloc((void **)&s.b.map_state, 512 * 60 * sizeof(int)));
+    HIP_OK(hipMalloc((void **)&s.b.cnt_state, 4096 * 2 * sizeof(int)));
+    return true;
+}
+
+static void slot_free(Slot &s) {
+    hipFree(s.b.rec1); hipFree(s.b.s2rec); hipFree(s.b.pxs); hipFree(s.b.s3rec); hipFree(s.b.z); hipFree(s.b.cnt);
+    hipFree(s.b.ev_off); hipFree(s.b.table); hipFree(s.b.scan_sums); hipFree(s.b.totals); hipFree(s.b.ctx_state);
+    hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events); hipFree(s.b.touch); hipFree(s.b.puv);
+    hipFree(s.b.coded); hipFree(s.d_img);
+    if (s.h_totals) hipHostFree(s.h_totals);
+    if (s.h_coded) hipHostFree(s.h_coded);
+    for (auto &e : s.tm.ev) if (e) hipEventDestroy(e);
+    if (s.done) hipEventDestroy(s.done);
+    if (s.stream) hipStreamDestroy(s.stream);
+}
+
+static bool ensure_events(Slot &s, size_t n_ev) {
+    if (n_ev <= s.ev_cap) return true;
+    size_t cap = n_ev + n_ev / 8 + 1024;
+    if (!dev_alloc(s.b.events, cap) || !dev_alloc(s.b.touch, 2 * cap) || !dev_alloc(s.b.puv, 2 * cap) ||
+        !dev_alloc(s.b.coded, cap)) return false;
+    if (s.h_coded) hipHostFree(s.h_coded);
+    s.h_coded = nullptr;
+    HIP_OK(hipHostMalloc((void **)&s.h_coded, cap * sizeof(uint16_t), hipHostMallocDefault));
+    s.ev_cap = s.h_cap = cap;
+    return true;
+}
+
+static bool ensure_pixels(Slot &s, size_t n) {
+    if (n > s.px_cap) {
+        size_t cap = n;
+        if (!dev_alloc(s.b.rec1, cap) || !dev_alloc(s.b.s2rec, cap) || !dev_alloc(s.b.pxs, cap) ||
+            !dev_alloc(s.b.s3rec, cap) || !dev_alloc(s.b.z, cap) || !dev_alloc(s.b.cnt, cap) ||
+            !dev_alloc(s.b.ev_off, cap)) return false;
+        s.px_cap = cap;
+    }
+    return ensure_events(s, 6 * n);          // typical images need 4.3-4.5 bins/px; grown on demand
+}
+
+static bool launch_front(nblic_amd_ctx *c, Slot &s, const uint8_t *img, bool on_device, int h, int w) {
+    size_t n = size_t(h) * size_t(w);
+    if (!ensure_pixels(s, n)) return false;
+    if (on_device) {
+        s.b.img = img;
+    } else {
+        if (n > s.img_cap) { if (!dev_alloc(s.d_img, n)) return false; s.img_cap = n; }
+        HIP_OK(hipMemcpyAsync(s.d_img, img, n, hipMemcpyHostToDevice, s.stream));
+        s.b.img = s.d_img;
+    }
+    s.h = h; s.w = w;
+    e1_init_state(s.b, s.stream);
+    e1_launch_front(s.b, h, w, s.stream, c->timing ? &s.tm : nullptr);
+    HIP_OK(hipMemcpyAsync(s.h_totals, s.b.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+    return true;
+}
+
+static bool launch_back(nblic_amd_ctx *c, Slot &s) {
+    HIP_OK(hipStreamSynchronize(s.stream));
+    s.n_ev = s.h_totals[2];
+    if (s.n_ev >= 0x7FFFFFFFu) { fprintf(stderr, "[nblic_amd] event count overflow\n"); return false; }
+    if (!ensure_events(s, s.n_ev)) return false;
+    e1_launch_back(s.b, s.h, s.w, s.n_ev, s.stream, c->timing ? &s.tm : nullptr);
+    HIP_OK(hipMemcpyAsync(s.h_coded, s.b.coded, size_t(s.n_ev) * sizeof(uint16_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_OK(hipEventRecord(s.done, s.stream));
+    return true;
+}
+
+static void collect_timing(nblic_amd_ctx *c, Slot &s) {
+    if (!c->timing) return;
+    for (int k = 0; k + 1 < kE1Marks; k++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.tm.ev[k], s.tm.ev[k + 1]) == hipSuccess) c->stage_ms[k] += ms;
+    }
+}
+
+static void release_slot(nblic_amd_ctx *c, int id, bool was_coding) {
+    { std::lock_guard<std::mutex> g(c->fm); c->free_slots.push_back(id); if (was_coding) c->coding--; }
+    c->fcv.notify_all();
+}
+
+static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *imgs, bool on_device, const int *hs,
+                         const int *ws, uint8_t *const *outs, const size_t *caps, long *lens) {
+    if (hipSetDevice(c->device) != hipSuccess) return false;
+    for (auto &v : c->stage_ms) v = 0;
+    c->total_bins = 0; c->coder_s = 0;
+    std::mutex stat_m;
+    std::deque<int> p1, p2;
+    int next = 0;
+    bool ok = true;
+    auto submit_coder = [&](Slot &s) {
+        collect_timing(c, s);
+        int job = s.job;
+        { std::lock_guard<std::mutex> g(c->fm); c->coding++; }
+        c->pool->submit([c, &s, job, outs, caps, lens, &stat_m] {
+            auto t0 = std::chrono::steady_clock::now();
+            long len = -1;
+            if (caps[job] >= size_t(kHeaderBytes) + 4) {
+                write_header(outs[job], s.h, s.w, 0, kMinKStep, 1);
+                size_t body = range_code(s.h_coded, s.n_ev, outs[job] + kHeaderBytes, caps[job] - kHeaderBytes);
+                if (body != SIZE_MAX) len = long(kHeaderBytes + body);
+                else fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", job, caps[job]);
+            }
+            lens[job] = len;
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            { std::lock_guard<std::mutex> g(stat_m); c->total_bins += double(s.n_ev); c->coder_s += dt; }
+            release_slot(c, s.id, true);
+        });
+    };
+    auto try_acquire = [&](int &id) {
+        std::lock_guard<std::mutex> g(c->fm);
+        if (c->free_slots.empty()) return false;
+        id = c->free_slots.front(); c->free_slots.pop_front();
+        return true;
+    };
+    for (;;) {
+        int id;
+        while (next < n_images && try_acquire(id)) {
+            Slot &s = c->slots[id];
+            int k = next++;
+            s.job = k; lens[k] = -1;
+            if (!size_ok(hs[k], ws[k], c->max_px) || !launch_front(c, s, imgs[k], on_device, hs[k], ws[k])) {
+                ok = false; release_slot(c, id, false); continue;
+            }
+            p1.push_back(id);
+        }
+        while (!p2.empty() && hipEventQuery(c->slots[p2.front()].done) == hipSuccess) {
+            submit_coder(c->slots[p2.front()]); p2.pop_front();
+        }
+        if (!p1.empty()) {
+            Slot &s = c->slots[p1.front()]; p1.pop_front();
+            if (launch_back(c, s)) p2.push_back(s.id);
+            else { ok = false; hipStreamSynchronize(s.stream); release_slot(c, s.id, false); }
+            continue;
+        }
+        if (!p2.empty()) {
+            Slot &s = c->slots[p2.front()]; p2.pop_front();
+            if (hipEventSynchronize(s.done) != hipSuccess) { ok = false; release_slot(c, s.id, false); continue; }
+            submit_coder(s);
+            continue;
+        }
+        if (next >= n_images) break;
+        std::unique_lock<std::mutex> g(c->fm);
+        c->fcv.wait(g, [c] { return !c->free_slots.empty(); });
+    }
+    {   // wait for the coder threads
+        std::unique_lock<std::mutex> g(c->fm);
+        c->fcv.wait(g, [c] { return c->coding == 0; });
+    }
+    for (int k = 0; k < n_images; k++) if (lens[k] < 0) ok = false;
+    return ok;
+}
+
+// ---- default context behind the drop-in entry points ---------------------------------------
+static nblic_amd_ctx *g_default = nullptr;
+static std::mutex g_default_m;
+
+static nblic_amd_ctx *default_ctx() {
+    std::lock_guard<std::mutex> g(g_default_m);
+    if (!g_default) {
+        const char *dev = getenv("NBLIC_AMD_DEVICE");
+        g_default = nblic_amd_create(dev ? atoi(dev) : 0, 2, 2);
+    }
+    return g_default;
+}
+
+}  // namespace nblic
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+size_t nblic_amd_range_code(const uint16_t *coded, size_t n, unsigned char *out, size_t cap) {
+    return range_code(coded, n, out, cap);
+}
+
+const char *nblic_amd_version(void) { return "nblic_amd 0.1 (NBLIC v0.3 bitstream, gfx950)"; }
+
+nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        fprintf(stderr, "[nblic_amd] no HIP device available -- this library has no CPU fallback\n");
+        return nullptr;
+    }
+    if (device < 0 || device >= count || hipSetDevice(device) != hipSuccess) {
+        fprintf(stderr, "[nblic_amd] cannot select HIP device %d of %d\n", device, count);
+        return nullptr;
+    }
+    if (n_slots < 1) n_slots = 1;
+    if (n_coders < 1) n_coders = 1;
+    auto *c = new nblic_amd_ctx;
+    c->device = device;
+    c->slots.resize(size_t(n_slots));
+    for (int i = 0; i < n_slots; i++) {
+        if (!slot_init(c->slots[size_t(i)], i)) { nblic_amd_destroy(c); return nullptr; }
+        c->free_slots.push_back(i);
+    }
+    if (!c->serial.init()) { nblic_amd_destroy(c); return nullptr; }
+    c->pool = new Pool(n_coders);
+    return c;
+}
+
+void nblic_amd_destroy(nblic_amd_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    delete c->pool;
+    for (auto &s : c->slots) slot_free(s);
+    c->serial.destroy();
+    delete c;
+}
+
+void nblic_amd_set_max_pixels(nblic_amd_ctx *c, long max_pixels) { c->max_px = max_pixels > 0 ? max_pixels : kMaxPixels; }
+void nblic_amd_enable_timing(nblic_amd_ctx *c, int on) { c->timing = on != 0; }
+
+int nblic_amd_stage_times(nblic_amd_ctx *c, double *ms, const char **names, int cap) {
+    int n = kE1Marks - 1;
+    for (int k = 0; k < n && k < cap; k++) { ms[k] = c->stage_ms[k]; if (names) names[k] = kE1StageNames[k]; }
+    return n < cap ? n : cap;
+}
+
+void nblic_amd_last_stats(nblic_amd_ctx *c, double *total_bins, double *coder_seconds_sum) {
+    if (total_bins) *total_bins = c->total_bins;
+    if (coder_seconds_sum) *coder_seconds_sum = c->coder_s;
+}
+
+int nblic_amd_encode_batch(nblic_amd_ctx *c, int n_images, const unsigned char *const *imgs, int imgs_on_device,
+                           const int *heights, const int *widths, unsigned char *const *outs, const size_t *out_caps,
+                           long *out_lens) {
+    if (!c || n_images < 0) return -1;
+    std::lock_guard<std::mutex> g(c->api);
+    return encode_batch(c, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps, out_lens) ? 0 : -1;
+}
+
+long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, int w, int which, void *out, size_t out_bytes) {
+    if (!c || !size_ok(h, w, c->max_px)) return -1;
+    std::lock_guard<std::mutex> g(c->api);
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    int id;
+    { std::unique_lock<std::mutex> l(c->fm); c->fcv.wait(l, [c] { return !c->free_slots.empty(); }); id = c->free_slots.front(); c->free_slots.pop_front(); }
+    Slot &s = c->slots[size_t(id)];
+    long count = -1;
+    size_t n = size_t(h) * size_t(w);
+    if (launch_front(c, s, img, false, h, w) && launch_back(c, s) && hipStreamSynchronize(s.stream) == hipSuccess) {
+        const void *src = nullptr; size_t esz = 0, cnt = 0;
+        switch (which) {
+            case 0: src = s.b.rec1; esz = 4; cnt = n; break;
+            case 1: src = s.b.pxs; esz = 2; cnt = n; break;
+            case 2: src = s.b.z; esz = 1; cnt = n; break;
+            case 3: src = s.b.cnt; esz = 1; cnt = n; break;
+            case 4: src = s.b.events; esz = 4; cnt = s.n_ev; break;
+            case 5: src = s.b.coded; esz = 2; cnt = s.n_ev; break;
+            default: break;
+        }
+        if (src && cnt * esz <= out_bytes && hipMemcpy(out, src, cnt * esz, hipMemcpyDeviceToHost) == hipSuccess) count = long(cnt);
+    }
+    release_slot(c, id, false);
+    return count;
+}
+
+// ---- drop-in entry points --------------------------------------------------------------------
+int NBLICcompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int height, int width, int *p_near, int *p_effort) {
+    (void)verbose;
+    *p_near = iclip(*p_near, 0, kMaxNear);                                   // NBLIC.c:768
+    *p_effort = iclip(*p_effort, 1, 3);                                      // NBLIC.c:770
+    int k_step = k_step_for_near(*p_near);
+    write_header(p_buf, height, width, *p_near, k_step, *p_effort);          // the reference writes it before validating
+    if (!size_ok(height, width, kMaxPixels)) return -1;
+    nblic_amd_ctx *c = default_ctx();
+    if (!c) return -1;
+    if (*p_near == 0 && *p_effort == 1) {
+        const unsigned char *imgs[1] = {p_img};
+        unsigned char *outs[1] = {p_buf};
+        size_t caps[1] = {SIZE_MAX};
+        long lens[1] = {-1};
+        if (nblic_amd_encode_batch(c, 1, imgs, 0, &height, &width, outs, caps, lens) != 0) return -1;
+        return int(lens[0]);
+    }
+    std::lock_guard<std::mutex> g(c->api);
+    return int(c->serial.encode(p_buf, p_img, height, width, *p_near, k_step, *p_effort, c->device));
+}
+
+int NBLICdecompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int *p_height, int *p_width, int *p_near, int *p_effort) {
+    (void)verbose;
+    if (memcmp(p_buf, "NBLIC0.3", 8) != 0) return -1;                        // NBLIC.c:698-712
+    int n_channel = p_buf[8];
+    *p_height = (p_buf[9] << 8) | p_buf[10];
+    *p_width = (p_buf[11] << 8) | p_buf[12];
+    *p_near = p_buf[13];
+    int k_step = p_buf[14];
+    *p_effort = p_buf[15];
+    if (!size_ok(*p_height, *p_width, kMaxPixels) || n_channel > 1 || *p_near > kMaxNear || k_step < kMinKStep ||
+        k_step > kLevels || *p_effort < 1 || *p_effort > 3) return -1;       // NBLIC.c:733-745
+    nblic_amd_ctx *c = default_ctx();
+    if (!c) return -1;
+    std::lock_guard<std::mutex> g(c->api);
+    return c->serial.decode(p_buf, p_img, *p_height, *p_width, *p_near, k_step, *p_effort, c->device);
+}
+
+int QNBLICcompress(uint16_t *p_buf, unsigned char *p_img, int height, int width) {
+    (void)p_buf; (void)p_img; (void)height; (void)width;
+    fprintf(stderr, "[nblic_amd] QNBLICcompress: effort-0 path not built yet in this round\n");
+    return -1;
+}
+int QNBLICdecompress(uint16_t *p_buf, unsigned char *p_img, int *p_height, int *p_width) {
+    (void)p_buf; (void)p_img; (void)p_height; (void)p_width;
+    fprintf(stderr, "[nblic_amd] QNBLICdecompress: effort-0 path not built yet in this round\n");
+    return -1;
+}
+int QNBLICcompressMultiThread(uint16_t *p_buf, unsigned char *p_img, int height, int width) {
+    return QNBLICcompress(p_buf, p_img, height, width);                      // QNBLIC.c:874-879 (non-Windows build)
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+// serial_engine.hip -- raster-serial NBLIC engine: one workgroup per image, model state in LDS.
+//
+// Used for everything that cannot be replayed per key: NBLICdecompress at any
+// setting, near-lossless encode, and the least-squares efforts 2/3.  Mirrors the reference's
+// fused loop (NBLIC.c:749-908) on the device: context table (8 KB), counter trees (32 KB) and
+// re-mappers (60 KB) sit in the CU's 160 KB LDS; the image, the stream and the least-squares
+// row statistics stay in HBM.  Round 1 drives the chain from a single lane -- it is a
+// correctness-first engine whose throughput comes from running many images at once, not from
+// one image; the wave-cooperative least-squares solve is listed in DESIGN.md as next work.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "model.h"
+#include "serial_engine.h"
+
+namespace nblic {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+constexpr int kLsqMaxN = 10, kLsqMaxM = 1 + kLsqMaxN + kLsqMaxN * kLsqMaxN;
+constexpr int kFb1 = 12, kFb2 = 2, kFb3 = 10, kDecayS = 3, kDecayV = 5;
+constexpr i64 kBiasInit = 8, kBiasMax = 4096, kBiasCoef = 21;
+
+__device__ __forceinline__ i64 mulw(i64 a, i64 b) { return i64(u64(a) * u64(b)); }    // wrapping, NBLIC.c:139
+__device__ __forceinline__ i64 abs64(i64 v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ i64 clip64(i64 v, i64 lo, i64 hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ i64 decay(i64 v, int ab) { return (mulw(v, ab - 1) + ab / 2) / ab; }   // NBLIC.c:199,273-279
+
+struct SerialArgs {
+    uint8_t *img; uint8_t *stream; size_t stream_cap;
+    int h, w, near, k_step, effort, decode;
+    i64 *stats; long *len_out;
+};
+
+// ---- range coder on the device (NBLIC.c:527-586) -------------------------------------------
+struct DevCoder {
+    uint8_t *p, *end;
+    uint32_t lo, hi, window;
+    bool overflow;
+};
+
+template <bool DEC>
+__device__ __forceinline__ int coder_bin(DevCoder &rc, int bin, uint32_t prob) {
+    uint32_t cut = rc.lo + uint32_t((u64(rc.hi - rc.lo) * prob) >> 12);
+    if (DEC) bin = rc.window <= cut;
+    if (bin) rc.hi = cut; else rc.lo = cut + 1;
+    while (((rc.lo ^ rc.hi) >> 24) == 0) {
+        if (rc.p < rc.end) {
+            if (DEC) rc.window = (rc.window << 8) | *rc.p; else *rc.p = uint8_t(rc.hi >> 24);
+        } else { rc.overflow = true; if (DEC) rc.window <<= 8; }
+        rc.p++;
+        rc.lo <<= 8; rc.hi = (rc.hi << 8) | 0xFFu;
+    }
+    return bin;
+}
+
+// ---- least-squares predictor (NBLIC.c:112-283); vectors are [s | b(n) | A(n x n)] ----------
+__device__ int lsq_solve(int n, i64 *A, i64 *b) {                        // NBLIC.c:112-161
+    for (int k = 0; k + 1 < n; k++) {
+        int piv = k;
+        for (int i = k + 1; i < n; i++) if (abs64(A[i * n + k]) > abs64(A[piv * n + k])) piv = i;
+        if (piv != k) {
+            i64 t = b[k]; b[k] = b[piv]; b[piv] = t;
+            for (int j = k; j < n; j++) { t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+        }
+        i64 d = A[k * n + k];
+        if (d == 0) return 0;
+        for (int i = k + 1; i < n; i++) {
+            i64 l = A[i * n + k];
+            A[i * n + k] = 0;
+            if (l == 0) continue;
+            for (int j = k + 1; j < n; j++) A[i * n + j] -= mulw(A[k * n + j], l) / d;
+            b[i] -= mulw(b[k], l) / d;
+        }
+    }
+    for (int k = n - 1; k > 0; k--) {
+        i64 d = A[k * n + k];
+        if (d == 0) return 0;
+        for (int i = 0; i < k; i++) {
+            i64 l = A[i * n + k];
+            A[i * n + k] = 0;
+            if (l != 0) b[i] -= mulw(b[k], l) / d;
+        }
+    }
+    return 1;
+}
+
+__device__ int lsq_predict(int n, int m, const i64 *E, const i64 *F, const i64 *vn, i64 bias, i64 *px_q12) {   // :210-239
+    i64 sys[kLsqMaxM];
+    i64 *b = sys + 1, *A = sys + 1 + n;
+    for (int k = 1; k < m; k++) sys[k] = E[k] + F[k];
+    for (int k = 0; k < n; k++) { b[k] += bias * (1 << kFb3); A[k * n + k] += bias * n; }
+    if (!lsq_solve(n, A, b)) return 0;
+    i64 px = i64(kMid) << kFb1;
+    for (int k = 0; k < n; k++) {
+        i64 d = A[k * n + k];
+        px += (mulw(mulw(b[k], vn[k]), 1 << kFb2) + (d >> 1)) / d;
+    }
+    *px_q12 = clip64(px, 0, i64(kMaxVal) << kFb1);
+    return 1;
+}
+
+__device__ void lsq_update(int n, int m, i64 *E, i64 *B, const i64 *vn, int x, i64 s_curr, i64 s_sum) {        // :242-283
+    i64 xc = x - kMid;
+    s_sum = clip64(s_sum + (1 << kFb1), 1 << kFb1, 16 << kFb1);
+    i64 half = s_sum >> 1;
+    for (int k = 0; k < m; k++) {
+        i64 sample;
+        if (k == 0) sample = s_curr;
+        else if (k <= n) sample = (mulw(xc * vn[k - 1], i64(1) << (4 + kFb1 + kFb1)) + half) / s_sum;
+        else { int r = (k - 1 - n) / n, c = (k - 1 - n) % n; sample = (mulw(vn[r] * vn[c], i64(1) << (4 + kFb2 + kFb1)) + half) / s_sum; }
+        int ab = k ? kDecayV : kDecayS;
+        B[k] = decay(B[k], ab) + sample;
+        E[k] = decay(E[k], ab) + B[k];
+    }
+}
+
+// ---- the engine ------------------------------------------------------------------------------
+struct Lds {
+    int     ctx[kContexts];
+    int     c0[kLevels][kTreeNodes], c1[kLevels][kTreeNodes];
+    int     count[512][kMapSyms];
+    uint8_t rank_of[512][kMapSyms], sym_at[512][kMapSyms];
+};
+
+template <bool DEC>
+__device__ void run_engine(const SerialArgs &a, Lds &S) {
+    const int w = a.w, h = a.h, near = a.near, k_step = a.k_step;
+    const int n = a.effort == 2 ? 6 : (a.effort == 3 ? 10 : 0);                    // N_LIST, NBLIC.c:88
+    const int m = 1 + n + n * n;
+    uint8_t *img = a.img;
+    i64 *Brow = a.stats, *Frow = a.stats + size_t(w) * m;
+    i64 E[kLsqMaxM], vn[kLsqMaxN];
+    i64 bias = kBiasInit;
+
+    DevCoder rc{a.stream + kHeaderBytes, a.stream + a.stream_cap, 0u, 0xFFFFFFFFu, 0u, false};
+    if (DEC) for (int k = 0; k < 4; k++) rc.window = (rc.window << 8) | *rc.p++;
+
+    auto pix = [&](int r, int c) { return int(img[size_t(r) * size_t(w) + size_t(c)]); };
+
+    for (int i = 0; i < h; i++) {
+        int err = 0;
+        if (n > 0) {                                                               // NBLIC.c:817-820, 186-204
+            for (int k = 0; k < m; k++) E[k] = 0;
+            for (int j = w - 1; j >= 0; j--)
+                for (int k = 0; k < m; k++) {
+                    i64 carry = (j == w - 1) ? 0 : decay(Frow[size_t(j + 1) * m + k], k ? kDecayV : kDecayS);
+                    Frow[size_t(j) * m + k] = carry + Brow[size_t(j) * m + k];
+                }
+        }
+        for (int j = 0; j < w; j++) {
+            Taps t = sample_taps(pix, w, i, j);
+            i64 b1 = 0, b2 = 0, p1 = 0, p2 = 0;
+            int ok1 = 0, ok2 = 0, px0;
+            i64 *B = nullptr, *F = nullptr;
+            if (n > 0) {                                                           // NBLIC.c:831-846
+                const int order[kLsqMaxN] = {t.a, t.b, t.c, t.d, t.e, t.f, t.t, t.h, t.q, t.g};
+                for (int k = 0; k < n; k++) vn[k] = order[k] - kMid;
+                B = Brow + size_t(j) * m; F = Frow + size_t(j) * m;
+                b1 = bias * kBiasCoef / (kBiasCoef + 1);
+                b2 = bias * (kBiasCoef + 1) / kBiasCoef;
+                b1 = clip64(clip64(b1, -1, bias - 1), 0, kBiasMax);
+                b2 = clip64(clip64(b2, bias + 1, kBiasMax + 1), 0, kBiasMax);
+                ok1 = lsq_predict(n, m, E, F, vn, b1, &p1);
+                ok2 = lsq_predict(n, m, E, F, vn, b2, &p2);
+            }
+            if (ok1) px0 = int((p1 + (1 << (kFb1 - 1))) >> kFb1);
+            else { px0 = predict(t); p1 = i64(px0) << kFb1; }
+
+            Level L = quantise(activity(t, err));
+            int adr = context_address(t, L.qu, px0);
+            int v = S.ctx[adr];
+            int sign = bias_sign(v), px = bias_apply(v, px0);
+            int mk = px * 2 + sign;
+
+            auto step = [&](int qu, int qv, int node, int bin) {                   // NBLIC.c:628-637
+                int u0 = S.c0[qu][node], u1 = S.c1[qu][node], v0 = S.c0[qv][node], v1 = S.c1[qv][node];
+                int prob = mix_prob(counter_p1(u0, u1), counter_p1(v0, v1), L.qw);
+                bin = coder_bin<DEC>(rc, bin, uint32_t(prob));
+                Counter cu{u0, u1};
+                counter_add(cu, bin, kWeightOne - L.qw);
+                S.c0[qu][node] = cu.c0; S.c1[qu][node] = cu.c1;
+                Counter cv{S.c0[qv][node], S.c1[qv][node]};                        // re-read: qu may equal qv
+                counter_add(cv, bin, L.qw);
+                S.c0[qv][node] = cv.c0; S.c1[qv][node] = cv.c1;
+                return bin;
+            };
+
+            int y;
+            if (!DEC) {
+                y = residual_to_symbol(pix(i, j), px, sign, near);
+                walk_symbol(k_step, L.qu, L.qv, y < kMapSyms ? int(S.rank_of[mk][y]) : y, step);
+            } else {
+                int z = walk_symbol(k_step, L.qu, L.qv, -1, step);
+                y = z < kMapSyms ? int(S.sym_at[mk][z]) : z;
+            }
+            if (y < kMapSyms) {                                                    // NBLIC.c:497-523
+                int z = S.rank_of[mk][y];
+                int c = ++S.count[mk][z];
+                if (z > 0 && S.count[mk][z - 1] < c) {
+                    int other = S.sym_at[mk][z - 1];
+                    S.count[mk][z] = S.count[mk][z - 1]; S.count[mk][z - 1] = c;
+                    S.sym_at[mk][z] = uint8_t(other); S.sym_at[mk][z - 1] = uint8_t(y);
+                    S.rank_of[mk][y] = uint8_t(z - 1); S.rank_of[mk][other] = uint8_t(z);
+                }
+            }
+            int xr = symbol_to_pixel(y, px, sign, near);
+            img[size_t(i) * size_t(w) + size_t(j)] = uint8_t(xr);
+            err = clip_err(xr, px0);
+            S.ctx[adr] = bias_update(v, err);
+
+            if (n > 0) {                                                           // NBLIC.c:882-893
+                i64 xq = i64(xr) << kFb1;
+                i64 s_curr = abs64(p1 - xq);
+                i64 s_sum = (E[0] + F[0]) + s_curr * kDecayS / (kDecayS - 1);
+                lsq_update(n, m, E, B, vn, xr, s_curr, s_sum);
+                if (ok1 && ok2) bias = (abs64(p1 - xq) > abs64(p2 - xq)) ? b2 : b1;
+            }
+        }
+    }
+    if (!DEC) for (int k = 0; k < 4; k++) {                                        // NBLIC.c:576-586
+        if (rc.p < rc.end) *rc.p = uint8_t(rc.lo >> 24); else rc.overflow = true;
+        rc.p++; rc.lo <<= 8;
+    }
+    *a.len_out = rc.overflow ? -1L : long(rc.p - a.stream);
+}
+
+__global__ void __launch_bounds__(64) k_serial_codec(SerialArgs a) {
+    __shared__ Lds S;
+    for (int k = int(threadIdx.x); k < kContexts; k += 64) S.ctx[k] = 0;
+    for (int k = int(threadIdx.x); k < kLevels * kTreeNodes; k += 64) { (&S.c0[0][0])[k] = kWeightOne; (&S.c1[0][0])[k] = kWeightOne; }
+    for (int k = int(threadIdx.x); k < 512 * kMapSyms; k += 64) {
+        int s = k % kMapSyms;
+        (&S.count[0][0])[k] = 2 * (kMapSyms - 1 - s); (&S.rank_of[0][0])[k] = uint8_t(s); (&S.sym_at[0][0])[k] = uint8_t(s);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (a.decode) run_engine<true>(a, S); else run_engine<false>(a, S);
+}
+
+// ---- host side -------------------------------------------------------------------------------
+#define SE_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    fprintf(stderr, "[nblic_amd] %s failed: %s\n", #call, hipGetErrorString(e_)); return -1; } } while (0)
+
+bool SerialEngine::init() {
+    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+    return hipMalloc((void **)&d_len, sizeof(long)) == hipSuccess;
+}
+
+void SerialEngine::destroy() {
+    hipFree(d_img); hipFree(d_stream); hipFree(d_stats); hipFree(d_len);
+    if (stream) hipStreamDestroy(stream);
+    d_img = d_stream = nullptr; d_stats = nullptr; d_len = nullptr; stream = nullptr;
+}
+
+static long run_serial(SerialEngine &e, uint8_t *host_img, const uint8_t *host_in, size_t in_len, uint8_t *host_out,
+                       int h, int w, int near, int k_step, int effort, bool decode, int device) {
+    SE_OK(hipSetDevice(device));
+    size_t n = size_t(h) * size_t(w);
+    size_t cap = decode ? in_len + 8 : 2 * n + 4096;
+    int lsq_n = effort == 2 ? 6 : (effort == 3 ? 10 : 0);
+    size_t stats = lsq_n ? 2 * size_t(w) * size_t(1 + lsq_n + lsq_n * lsq_n) : 0;
+    if (n > e.img_cap) { hipFree(e.d_img); e.d_img = nullptr; SE_OK(hipMalloc((void **)&e.d_img, n)); e.img_cap = n; }
+    if (cap > e.stream_cap) { hipFree(e.d_stream); e.d_stream = nullptr; SE_OK(hipMalloc((void **)&e.d_stream, cap)); e.stream_cap = cap; }
+    if (stats > e.stats_cap) { hipFree(e.d_stats); e.d_stats = nullptr; SE_OK(hipMalloc((void **)&e.d_stats, stats * sizeof(int64_t))); e.stats_cap = stats; }
+    if (stats) SE_OK(hipMemsetAsync(e.d_stats, 0, stats * sizeof(int64_t), e.stream));        // NBLIC.c:789
+    if (decode) {
+        SE_OK(hipMemsetAsync(e.d_stream, 0, cap, e.stream));
+        SE_OK(hipMemcpyAsync(e.d_stream, host_in, in_len, hipMemcpyHostToDevice, e.stream));
+    } else {
+        SE_OK(hipMemcpyAsync(e.d_img, host_img, n, hipMemcpyHostToDevice, e.stream));
+    }
+    SerialArgs a{e.d_img, e.d_stream, cap, h, w, near, k_step, effort, decode ? 1 : 0, (long long *)e.d_stats, e.d_len};
+    hipLaunchKernelGGL(k_serial_codec, dim3(1), dim3(64), 0, e.stream, a);
+    long len = -1;
+    SE_OK(hipMemcpyAsync(&len, e.d_len, sizeof(long), hipMemcpyDeviceToHost, e.stream));
+    SE_OK(hipStreamSynchronize(e.stream));
+    if (len < 0) { fprintf(stderr, "[nblic_amd] serial engine: stream buffer exhausted\n"); return -1; }
+    SE_OK(hipMemcpy(host_img, e.d_img, n, hipMemcpyDeviceToHost));                           // reconstruction / decoded image
+    if (!decode) SE_OK(hipMemcpy(host_out + kHeaderBytes, e.d_stream + kHeaderBytes, size_t(len) - kHeaderBytes, hipMemcpyDeviceToHost));
+    return len;
+}
+
+long SerialEngine::encode(uint8_t *out, uint8_t *img, int h, int w, int near, int k_step, int effort, int device) {
+    return run_serial(*this, img, nullptr, 0, out, h, w, near, k_step, effort, false, device);
+}
+
+// How many bytes of the caller's stream may be read.  The reference's decoder reads exactly the
+// bytes the encoder wrote and its ABI carries no length (NBLIC.h:72), so the copy to the device
+// is bounded by the end of the readable mapping that holds `p` and by the CLI's 2 B/px provision.
+static size_t readable_span(const uint8_t *p, size_t want) {
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f) return want;
+    unsigned long lo, hi, addr = (unsigned long)p, end = 0;
+    char perms[8], line[512];
+    while (fgets(line, sizeof line, f)) {
+        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perms) != 3 || perms[0] != 'r') { if (end) break; continue; }
+        if (!end) { if (addr >= lo && addr < hi) end = hi; }
+        else if (lo == end) end = hi;                                   // contiguous readable mapping
+        else break;
+    }
+    fclose(f);
+    if (!end) return want;
+    size_t avail = size_t(end - addr);
+    return avail < want ? avail : want;
+}
+
+int SerialEngine::decode(const uint8_t *in, uint8_t *img, int h, int w, int near, int k_step, int effort, int device) {
+    size_t want = 2 * size_t(h) * size_t(w) + 4096;
+    size_t len = readable_span(in, want);
+    long r = run_serial(*this, img, in, len, nullptr, h, w, near, k_step, effort, true, device);
+    return r < 0 ? -1 : 0;
+}
+
+}  // namespace nblic

@@ -1,0 +1,139 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the oracle and the
+committed golden fixtures.  Bit-exact is the bar for every stage and every stream."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def unpack_rec1(r):
+    r = r.astype(np.uint32)
+    px0 = r & 0xFF
+    adr = (r >> 8) & 0x7FF
+    qw = (r >> 19) & 31
+    qu = (((r >> 16) & 7) << 1) | ((r >> 24) & 1)
+    rel = (r >> 25) & 3
+    qv = np.where(rel == 0, qu, np.where(rel == 1, qu + 1, qu - 1))
+    return px0, adr, qu, qv, qw
+
+
+STAGE_SHAPES = [(1, 1), (1, 9), (9, 1), (2, 2), (3, 5), (17, 13), (40, 37), (64, 64), (96, 128), (5, 300)]
+
+
+@pytest.mark.parametrize("shape", STAGE_SHAPES)
+def test_stage_parity(gpu_ctx, oracle, shape):
+    h, w = shape
+    for content in ("syn1", "noise", "checker", "const", "ramp"):
+        img = inputs.make(content, h, w)
+        st = oracle.stages(img)
+        px0, adr, qu, qv, qw = unpack_rec1(gpu_ctx.debug_stage(img, "rec1"))
+        assert np.array_equal(px0, st["px0"]), ("px0", content)
+        assert np.array_equal(adr, st["adr"]), ("adr", content)
+        assert np.array_equal(qu, st["qu"]) and np.array_equal(qv, st["qv"]) and np.array_equal(qw, st["qw"]), ("level", content)
+        pxs = gpu_ctx.debug_stage(img, "pxs")
+        assert np.array_equal(pxs & 0xFF, st["px"]) and np.array_equal(pxs >> 8, st["sign"]), ("S2", content)
+        assert np.array_equal(gpu_ctx.debug_stage(img, "z"), st["z"]), ("S3", content)
+        assert np.array_equal(gpu_ctx.debug_stage(img, "cnt"), st["ev_count"]), ("S4 count", content)
+        ev = gpu_ctx.debug_stage(img, "events")
+        assert len(ev) == len(st["cu"])
+        e_qu, e_qv, node = ev & 15, (ev >> 4) & 15, (ev >> 8) & 255
+        assert np.array_equal(e_qu * 256 + node, st["cu"]) and np.array_equal(e_qv * 256 + node, st["cv"]), ("S4 path", content)
+        assert np.array_equal((ev >> 16) & 31, st["ev_qw"]) and np.array_equal((ev >> 21) & 1, st["ev_bin"]), ("S4 bins", content)
+        coded = gpu_ctx.debug_stage(img, "coded")
+        assert np.array_equal(coded & 0xFFF, st["prob"]), ("S5 prob", content)
+        assert np.array_equal(coded >> 15, st["ev_bin"]), ("S5 bin", content)
+
+
+def test_batch_streams_equal_golden(gpu_ctx, golden):
+    _, streams = golden
+    imgs, want = [], []
+    for (h, w) in inputs.SMALL_SHAPES:
+        for content in inputs.CONTENTS:
+            imgs.append(inputs.make(content, h, w))
+            want.append(streams[inputs.case_id(content, h, w, 0, 1)].tobytes())
+    got = gpu_ctx.encode_batch(imgs)
+    for k, (g, wnt) in enumerate(zip(got, want)):
+        assert g == wnt, k
+
+
+def test_mixed_size_batch_equals_oracle(gpu_ctx, oracle):
+    from oracle.oracle import syn1
+    imgs = [syn1(512, 512, 1), inputs.make("noise", 300, 200), syn1(768, 512, 5), inputs.make("const", 1, 1),
+            syn1(100, 1000, 3), inputs.make("checker", 257, 255), syn1(512, 768, 2)]
+    got = gpu_ctx.encode_batch(imgs)
+    for img, g in zip(imgs, got):
+        assert g == oracle.encode(img, 0, 1)[0], img.shape
+
+
+def test_output_capacity_is_enforced(gpu_ctx):
+    img = inputs.make("noise", 64, 64)
+    outs = [np.empty(600, np.uint8)]                      # noise needs > 4 KB
+    with pytest.raises(RuntimeError):
+        gpu_ctx.encode_ptrs([img.ctypes.data], [img.shape], False, outs)
+
+
+def test_config2_4096_golden_and_round_trip(gpu_ctx, golden, oracle):
+    """BASELINE config 2: 4096x4096 SYN-1, -n0 -e1.  Golden hash from the compiled reference;
+    the stream must also decode (oracle decoder) back to the input."""
+    from oracle.oracle import syn1
+    manifest, _ = golden
+    m = manifest["large"]["syn1s1_4096x4096_n0_e1"]
+    img = syn1(4096, 4096, 1)
+    assert sha(img.tobytes()) == m["input_sha256"]
+    s = gpu_ctx.encode_batch([img])[0]
+    assert len(s) == m["len"] == 8900446
+    assert sha(s) == m["sha256"]
+    dec = oracle.decode(s)
+    assert dec is not None and np.array_equal(dec[0], img)
+
+
+def test_device_resident_inputs(gpu_ctx, oracle):
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import syn1
+    imgs = [syn1(256, 384, s) for s in (1, 2, 3, 4)]
+    dev = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    outs, lens = gpu_ctx.encode_ptrs([d.data_ptr() for d in dev], [i.shape for i in imgs], True)
+    for img, o, n in zip(imgs, outs, lens):
+        assert o[:int(n)].tobytes() == oracle.encode(img, 0, 1)[0]
+
+
+# ---- drop-in entry points, every mode (serial engine for everything but -n0 -e1) ------------
+@pytest.mark.parametrize("near,effort", inputs.PARAM_CLASSES)
+def test_dropin_compress_all_modes_small(pkg, golden, near, effort):
+    manifest, streams = golden
+    for (h, w) in [(1, 1), (1, 7), (7, 1), (3, 5), (17, 13)]:
+        for content in ("syn1", "noise", "checker"):
+            img = inputs.make(content, h, w)
+            cid = inputs.case_id(content, h, w, near, effort)
+            s, rec, n_out, e_out = pkg.compress(img, near, effort)
+            assert s == streams[cid].tobytes(), cid
+            m = manifest["small"][cid]
+            assert (n_out, e_out) == (m["near_out"], m["effort_out"])
+            assert sha(rec.tobytes()) == m["recon_sha256"], cid
+
+
+@pytest.mark.parametrize("near,effort", [(0, 1), (2, 1), (0, 2), (3, 3)])
+def test_dropin_decompress_reference_streams(pkg, golden, oracle, near, effort):
+    _, streams = golden
+    for (h, w) in [(1, 1), (2, 2), (5, 3), (17, 13), (64, 64) if effort == 1 else (17, 13)]:
+        img = inputs.make("syn1", h, w)
+        s = streams[inputs.case_id("syn1", h, w, near, effort)].tobytes()
+        d = pkg.decompress(s)
+        assert d is not None
+        want = oracle.decode(s)
+        assert np.array_equal(d[0], want[0]) and d[1:] == want[1:]
+        assert int(np.abs(d[0].astype(int) - img.astype(int)).max()) <= near
+
+
+def test_dropin_rejects_bad_input(pkg):
+    assert pkg.decompress(b"Q0.2" + bytes(60)) is None                  # not an NBLIC stream
+    assert pkg.compress(np.zeros((1, 1), np.uint8), 0, 1)[0] is not None
