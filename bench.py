@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixel/s of bit-exact -n0 -e1 NBLIC encode on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of B synthetic 4096x4096 8-bit gray
+frames (SYN-1, BASELINE config 2) per GPU: the frames are already resident in HBM when the
+timed region starts; the step ends when every byte-exact .nblic stream is in host memory
+(and, for N > 1, gathered on rank 0 over RCCL).  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+"""
+import argparse
+import hashlib
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy
+
+
+def cpu_baseline(frames, reps_budget_s=12.0):
+    """Single-thread CPU encode of the same frames: the compiled reference when oracle/_ref
+    travelled with the snapshot, else our CPU port.  Bounded sample (a few frames)."""
+    from oracle.oracle import Oracle, Reference
+    if Reference.available():
+        enc, kind = Reference().encode, "reference"
+    else:
+        o = Oracle()
+        enc, kind = (lambda im, n, e: o.encode(im, n, e)), "port"
+    px, t_total, used = 0, 0.0, 0
+    for f in frames:
+        t0 = time.perf_counter()
+        enc(f, 0, 1)
+        t_total += time.perf_counter() - t0
+        px += f.size
+        used += 1
+        if t_total > reps_budget_s:
+            break
+    return {"value": round(px / t_total / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": kind,
+            "sample": f"{used} of the batch's {frames[0].shape[0]}x{frames[0].shape[1]} SYN-1 frames, -n0 -e1, one thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=4096)
+    ap.add_argument("--width", type=int, default=4096)
+    ap.add_argument("--coders", type=int, default=0, help="host range-coder threads per GPU (0 = CPU share)")
+    ap.add_argument("--slots", type=int, default=0, help="images in flight per GPU (0 = min(batch, 16))")
+    ap.add_argument("--host-inputs", action="store_true", help="hand host buffers over (PCIe-inclusive rate)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = importlib.import_module("nblic-image-compression_amd")
+    H, W, B = args.height, args.width, args.batch
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    coders = args.coders or max(1, min(B, cpus // max(1, local_world)))
+    slots = args.slots or min(B, 16)
+
+    frames = [pkg.syn1(H, W, seed=rank * B + k + 1) for k in range(B)]
+    dev_frames = [torch.from_numpy(f).to(dev) for f in frames]
+    torch.cuda.synchronize()
+    ctx = pkg.Context(device=local_rank, n_slots=slots, n_coders=coders)
+    ctx.enable_timing(True)
+    outs = [np.empty(pkg.out_capacity(H, W), np.uint8) for _ in range(B)]
+    shapes = [(H, W)] * B
+    ptrs = [f.ctypes.data for f in frames] if args.host_inputs else [d.data_ptr() for d in dev_frames]
+    gather = None
+    if world > 1:
+        gather = importlib.import_module("nblic-image-compression_amd.gather")
+
+    last = {}
+
+    def step():
+        _, lens = ctx.encode_ptrs(ptrs, shapes, not args.host_inputs, outs)
+        last["lens"] = lens
+        if world > 1:
+            last["gathered"] = gather.gather_streams([o[:int(n)] for o, n in zip(outs, lens)], dev)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- reporting (outside the timed region) ------------------------------------------------
+    lens = last["lens"]
+    stage = ctx.stage_times()                         # summed over the B launches of the last step
+    bins, coder_s = ctx.last_stats()
+    per_launch = {k: v / B for k, v in stage.items() if k != "host_gap"}
+    dom = max(per_launch, key=per_launch.get)
+    alg_bytes = H * W + float(np.mean(lens))          # 1 B/px read + L/N B/px written
+    achieved = alg_bytes / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
+
+    bit_exact = None
+    if rank == 0:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
+                m = json.load(f)["large"].get(f"syn1s1_{H}x{W}_n0_e1")
+            if m:
+                s = outs[0][: int(lens[0])].tobytes()
+                bit_exact = (len(s) == m["len"] and hashlib.sha256(s).hexdigest() == m["sha256"])
+        except OSError:
+            pass
+
+    if rank == 0:
+        total_px = float(H) * W * B * world * args.steps
+        value = total_px / dt / 1e6
+        line = {
+            "metric": "Mpixel/s encode (bit-exact) 4096x4096 gray -e1 lossless",
+            "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{B} x {H}x{W} SYN-1 gray frames per GPU per step, -n0 -e1, inputs resident in HBM"
+                       if not args.host_inputs else f"{B} x {H}x{W} SYN-1 frames per GPU per step, -n0 -e1, host inputs (PCIe-inclusive)",
+                       "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders,
+                       "parallelism": f"image-per-GPU x{world}, RCCL gather of streams" if world > 1 else "single GPU"},
+            "bit_exact": bit_exact,
+            "bits_per_pixel": round(8.0 * float(np.mean(lens)) / (H * W), 4),
+            "bins_per_pixel": round(bins / (H * W * B), 3),
+            "host_coder_Mbins_per_s_per_thread": round(bins / coder_s / 1e6, 1) if coder_s > 0 else None,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "launch_ms": round(per_launch[dom], 4), "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "kernel_ms_per_image": {k: round(v, 4) for k, v in per_launch.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(frames)
+            line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 2)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,8 +79,9 @@ int nblic_amd_encode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned char
  * BASELINE.json exceeds the reference's own limit).  0 restores the reference limit.       */
 void nblic_amd_set_max_pixels(nblic_amd_ctx *ctx, long max_pixels);
 
-/* Per-stage device times of the LAST nblic_amd_encode_batch, measured with HIP events on the
- * streams the kernels ran on and summed over the batch's images.  Writes up to `cap` entries
+/* Per-kernel device times of the LAST nblic_amd_encode_batch: one HIP event in front of every
+ * launch, on the stream the kernel runs on, summed over the batch's images (divide by the
+ * image count for the average launch duration).  Writes up to `cap` entries
  * of milliseconds into ms[] and matching static strings into names[]; returns the count.
  * Timing is recorded only after nblic_amd_enable_timing(ctx, 1).                           */
 void nblic_amd_enable_timing(nblic_amd_ctx *ctx, int on);
@@ -100,6 +101,10 @@ long nblic_amd_debug_stage(nblic_amd_ctx *ctx, const unsigned char *img, int hei
  * Writes at most cap bytes (coder bytes + 4 flush bytes, no header); returns the byte count or
  * (size_t)-1 when cap is too small.  Needs no GPU.                                         */
 size_t nblic_amd_range_code(const uint16_t *coded, size_t n, unsigned char *out, size_t cap);
+
+/* Synthetic benchmark frame "SYN-1" (SURVEY.md 8d): xorshift32 noise on a triangular ramp with a
+ * 16-level texture; deterministic, integer only.  Host function, needs no GPU.              */
+void nblic_amd_syn1(unsigned char *img, int height, int width, uint32_t seed);
 
 const char *nblic_amd_version(void);
 

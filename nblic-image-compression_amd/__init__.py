@@ -33,7 +33,7 @@ EXPORTS = (
     "NBLICcompress", "NBLICdecompress", "QNBLICcompress", "QNBLICdecompress", "QNBLICcompressMultiThread",
     "nblic_amd_create", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_set_max_pixels",
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_stats", "nblic_amd_debug_stage",
-    "nblic_amd_range_code", "nblic_amd_version",
+    "nblic_amd_range_code", "nblic_amd_syn1", "nblic_amd_version",
 )
 
 
@@ -88,6 +88,8 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_debug_stage.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.nblic_amd_range_code.restype = C.c_size_t
     lib.nblic_amd_range_code.argtypes = [C.POINTER(C.c_uint16), C.c_size_t, _u8p, C.c_size_t]
+    lib.nblic_amd_syn1.restype = None
+    lib.nblic_amd_syn1.argtypes = [_u8p, C.c_int, C.c_int, C.c_uint32]
     lib.nblic_amd_version.restype = C.c_char_p
     _lib = lib
     return lib
@@ -133,6 +135,13 @@ def decompress(stream: bytes) -> Optional[Tuple[np.ndarray, int, int]]:
     if rc != 0:
         return None
     return img[:hh.value, :ww.value], n.value, e.value
+
+
+def syn1(h: int, w: int, seed: int = 1) -> np.ndarray:
+    """SYN-1 synthetic frame (``nblic_amd_syn1``)."""
+    img = np.empty((h, w), np.uint8)
+    load_library().nblic_amd_syn1(img.ctypes.data_as(_u8p), h, w, seed)
+    return img
 
 
 def range_code(coded: np.ndarray, cap: Optional[int] = None) -> Optional[bytes]:
@@ -202,9 +211,9 @@ class Context:
         return [o[:int(n)].tobytes() for o, n in zip(outs, lens)]
 
     def stage_times(self) -> dict:
-        ms = (C.c_double * 16)()
-        names = (C.c_char_p * 16)()
-        n = self.lib.nblic_amd_stage_times(self.handle, ms, names, 16)
+        ms = (C.c_double * 64)()
+        names = (C.c_char_p * 64)()
+        n = self.lib.nblic_amd_stage_times(self.handle, ms, names, 64)
         return {names[i].decode(): ms[i] for i in range(n)}
 
     def last_stats(self) -> Tuple[float, float]:

@@ -33,12 +33,23 @@ struct E1Buffers {
     uint16_t *coded;         // ev_cap   prob | bin<<15 for the host range coder
 };
 
-constexpr int kE1Marks = 12;
+// One HIP event before every kernel launch (and one after the last): interval k is exactly
+// kernel k of the launch sequence below, measured on the stream it runs on.
+constexpr int kE1Kernels = 26;
+constexpr int kE1Marks = kE1Kernels + 1;
 struct E1Timers { hipEvent_t ev[kE1Marks]; };
-// interval k = time between mark k and k+1 (interval 6 is the host read-back of the event total)
-static const char *const kE1StageNames[kE1Marks - 1] = {
-    "S1_predict", "part_adr", "S2_bias_chains", "part_mapper", "S3_mapper_chains",
-    "S4_count_scan", "host_gap", "S4_emit", "part_touch", "S5_counter_chains", "mix"};
+static const char *const kE1StageNames[kE1Kernels] = {
+    "k_predict",
+    "k_adr_count", "scan_reduce.adr", "scan_sums.adr", "scan_apply.adr", "k_adr_scatter",
+    "k_bias_chains",
+    "k_map_count", "scan_reduce.map", "scan_sums.map", "scan_apply.map", "k_map_scatter",
+    "k_mapper_chains",
+    "k_count_bins", "scan_reduce.bins", "scan_sums.bins", "scan_apply.bins",
+    "host_gap",
+    "k_emit_bins",
+    "k_touch_count", "scan_reduce.touch", "scan_sums.touch", "scan_apply.touch", "k_touch_scatter",
+    "k_counter_chains",
+    "k_mix"};
 
 void e1_init_state(const E1Buffers &b, hipStream_t s);
 void e1_launch_front(const E1Buffers &b, int h, int w, hipStream_t s, E1Timers *tm);

@@ -460,13 +460,18 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const T *in, uint32
 // ------------------------------------------------------------------------------------------
 static inline unsigned cdiv(size_t a, size_t b) { return unsigned((a + b - 1) / b); }
 
+struct Marker {                       // records one event in front of every launch
+    E1Timers *tm; hipStream_t s; int k;
+    void operator()() { if (tm) hipEventRecord(tm->ev[k], s); k++; }
+};
+
 template <class T>
-static void scan_exclusive(const T *in, uint32_t n, uint32_t *out, uint32_t *sums, uint32_t *total, hipStream_t s) {
+static void scan_exclusive(const T *in, uint32_t n, uint32_t *out, uint32_t *sums, uint32_t *total, hipStream_t s, Marker &mark) {
     unsigned nb = cdiv(n, kScanTile);
-    if (nb == 0) { hipMemsetAsync(total, 0, 4, s); return; }
-    hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb), dim3(kScanThreads), 0, s, in, n, sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, nb, total);
-    hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(kScanThreads), 0, s, in, n, sums, out);
+    if (nb == 0) { mark(); mark(); mark(); hipMemsetAsync(total, 0, 4, s); return; }
+    mark(); hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb), dim3(kScanThreads), 0, s, in, n, sums);
+    mark(); hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, nb, total);
+    mark(); hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(kScanThreads), 0, s, in, n, sums, out);
 }
 
 SegPlan make_plan(uint32_t n_items) {
@@ -484,48 +489,38 @@ void e1_init_state(const E1Buffers &b, hipStream_t s) {
 }
 
 // Stage group A: everything up to the per-pixel bin counts and their scan (the event total
-// is needed on the host before the event buffers can be sized).
+// is needed on the host before the event buffers can be sized).  17 launches.
 void e1_launch_front(const E1Buffers &b, int h, int w, hipStream_t s, E1Timers *tm) {
     const uint32_t n = uint32_t(size_t(h) * size_t(w));
     SegPlan pp = make_plan(n);
-    auto mark = [&](int k) { if (tm) hipEventRecord(tm->ev[k], s); };
-    mark(0);
-    hipLaunchKernelGGL(k_predict, dim3(cdiv(w, 256), h), dim3(256), 0, s, b.img, h, w, 0, h, b.rec1);
-    mark(1);
-    hipLaunchKernelGGL(k_adr_count, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.rec1, n, pp, b.table);
-    scan_exclusive<uint32_t>(b.table, uint32_t(kContexts) * pp.nseg, b.table, b.scan_sums, b.totals + 0, s);
-    hipLaunchKernelGGL(k_adr_scatter, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.rec1, b.img, n, pp, b.table, (uint2 *)b.s2rec);
-    mark(2);
-    hipLaunchKernelGGL(k_bias_chains, dim3(kContexts / 64), dim3(64), 0, s, (const uint2 *)b.s2rec, b.table, pp, n, b.ctx_state, b.pxs);
-    mark(3);
-    hipLaunchKernelGGL(k_map_count, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.img, b.pxs, n, pp, b.table);
-    scan_exclusive<uint32_t>(b.table, 512u * pp.nseg, b.table, b.scan_sums, b.totals + 1, s);
-    hipLaunchKernelGGL(k_map_scatter, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.img, b.pxs, n, pp, b.table, b.s3rec, b.z);
-    mark(4);
-    hipLaunchKernelGGL(k_mapper_chains, dim3(512 / 64), dim3(64), 0, s, b.s3rec, b.table, pp, 0u, b.totals + 1, b.map_state, b.z);
-    mark(5);
-    hipLaunchKernelGGL(k_count_bins, dim3(cdiv(n, 256)), dim3(256), 0, s, b.rec1, b.z, n, b.cnt);
-    scan_exclusive<uint8_t>(b.cnt, n, b.ev_off, b.scan_sums, b.totals + 2, s);
-    mark(6);
+    Marker mark{tm, s, 0};
+    mark(); hipLaunchKernelGGL(k_predict, dim3(cdiv(w, 256), h), dim3(256), 0, s, b.img, h, w, 0, h, b.rec1);
+    mark(); hipLaunchKernelGGL(k_adr_count, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.rec1, n, pp, b.table);
+    scan_exclusive<uint32_t>(b.table, uint32_t(kContexts) * pp.nseg, b.table, b.scan_sums, b.totals + 0, s, mark);
+    mark(); hipLaunchKernelGGL(k_adr_scatter, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.rec1, b.img, n, pp, b.table, (uint2 *)b.s2rec);
+    mark(); hipLaunchKernelGGL(k_bias_chains, dim3(kContexts / 64), dim3(64), 0, s, (const uint2 *)b.s2rec, b.table, pp, n, b.ctx_state, b.pxs);
+    mark(); hipLaunchKernelGGL(k_map_count, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.img, b.pxs, n, pp, b.table);
+    scan_exclusive<uint32_t>(b.table, 512u * pp.nseg, b.table, b.scan_sums, b.totals + 1, s, mark);
+    mark(); hipLaunchKernelGGL(k_map_scatter, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.img, b.pxs, n, pp, b.table, b.s3rec, b.z);
+    mark(); hipLaunchKernelGGL(k_mapper_chains, dim3(512 / 64), dim3(64), 0, s, b.s3rec, b.table, pp, 0u, b.totals + 1, b.map_state, b.z);
+    mark(); hipLaunchKernelGGL(k_count_bins, dim3(cdiv(n, 256)), dim3(256), 0, s, b.rec1, b.z, n, b.cnt);
+    scan_exclusive<uint8_t>(b.cnt, n, b.ev_off, b.scan_sums, b.totals + 2, s, mark);
+    mark();                                                     // start of the host gap (index 17)
 }
 
-// Stage group B: needs n_ev (read back from totals[2]) and event-sized buffers.
+// Stage group B: needs n_ev (read back from totals[2]) and event-sized buffers.  8 launches.
 void e1_launch_back(const E1Buffers &b, int h, int w, uint32_t n_ev, hipStream_t s, E1Timers *tm) {
     const uint32_t n = uint32_t(size_t(h) * size_t(w));
     SegPlan pe = make_plan(n_ev);
-    auto mark = [&](int k) { if (tm) hipEventRecord(tm->ev[k], s); };
-    mark(7);
-    hipLaunchKernelGGL(k_emit_bins, dim3(cdiv(n, 256)), dim3(256), 0, s, b.rec1, b.z, n, b.ev_off, b.events);
-    mark(8);
-    hipLaunchKernelGGL(k_touch_count, dim3(cdiv(pe.nseg, 4)), dim3(256), 0, s, b.events, n_ev, pe, b.table);
-    scan_exclusive<uint32_t>(b.table, 4096u * pe.nseg, b.table, b.scan_sums, b.totals + 3, s);
-    hipLaunchKernelGGL(k_touch_scatter, dim3(cdiv(pe.nseg, 4)), dim3(256), 0, s, b.events, n_ev, pe, b.table, (uint2 *)b.touch);
-    mark(9);
-    hipLaunchKernelGGL(k_counter_chains, dim3(4096), dim3(64), 0, s, (const uint2 *)b.touch, b.table, pe, b.totals + 3,
-                       (int2 *)b.cnt_state, b.puv);
-    mark(10);
-    hipLaunchKernelGGL(k_mix, dim3(cdiv(n_ev, 256)), dim3(256), 0, s, b.events, b.puv, n_ev, b.coded);
-    mark(11);
+    Marker mark{tm, s, 18};
+    mark(); hipLaunchKernelGGL(k_emit_bins, dim3(cdiv(n, 256)), dim3(256), 0, s, b.rec1, b.z, n, b.ev_off, b.events);
+    mark(); hipLaunchKernelGGL(k_touch_count, dim3(cdiv(pe.nseg, 4)), dim3(256), 0, s, b.events, n_ev, pe, b.table);
+    scan_exclusive<uint32_t>(b.table, 4096u * pe.nseg, b.table, b.scan_sums, b.totals + 3, s, mark);
+    mark(); hipLaunchKernelGGL(k_touch_scatter, dim3(cdiv(pe.nseg, 4)), dim3(256), 0, s, b.events, n_ev, pe, b.table, (uint2 *)b.touch);
+    mark(); hipLaunchKernelGGL(k_counter_chains, dim3(4096), dim3(64), 0, s, (const uint2 *)b.touch, b.table, pe, b.totals + 3,
+                               (int2 *)b.cnt_state, b.puv);
+    mark(); hipLaunchKernelGGL(k_mix, dim3(cdiv(n_ev, 256)), dim3(256), 0, s, b.events, b.puv, n_ev, b.coded);
+    mark();                                                     // index 26: end
 }
 
 }  // namespace nblic

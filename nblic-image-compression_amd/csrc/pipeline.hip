@@ -147,7 +147,8 @@ struct nblic_amd_ctx {
     std::deque<int> free_slots;
     int coding = 0;                       // S6 tasks outstanding
     // reporting
-    double stage_ms[kE1Marks - 1] = {0};
+    double stage_ms[kE1Kernels] = {0};
+    long stage_launches = 0;
     double total_bins = 0, coder_s = 0;
     SerialEngine serial;
 };
@@ -234,10 +235,11 @@ static bool launch_back(nblic_amd_ctx *c, Slot &s) {
 
 static void collect_timing(nblic_amd_ctx *c, Slot &s) {
     if (!c->timing) return;
-    for (int k = 0; k + 1 < kE1Marks; k++) {
+    for (int k = 0; k < kE1Kernels; k++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.tm.ev[k], s.tm.ev[k + 1]) == hipSuccess) c->stage_ms[k] += ms;
     }
+    c->stage_launches++;
 }
 
 static void release_slot(nblic_amd_ctx *c, int id, bool was_coding) {
@@ -249,6 +251,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
                          const int *ws, uint8_t *const *outs, const size_t *caps, long *lens) {
     if (hipSetDevice(c->device) != hipSuccess) return false;
     for (auto &v : c->stage_ms) v = 0;
+    c->stage_launches = 0;
     c->total_bins = 0; c->coder_s = 0;
     std::mutex stat_m;
     std::deque<int> p1, p2;
@@ -341,6 +344,18 @@ size_t nblic_amd_range_code(const uint16_t *coded, size_t n, unsigned char *out,
     return range_code(coded, n, out, cap);
 }
 
+void nblic_amd_syn1(unsigned char *img, int h, int w, uint32_t seed) {
+    uint32_t xs = seed;
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            xs ^= xs << 13; xs ^= xs >> 17; xs ^= xs << 5;
+            int t = ((i + 2 * j) >> 3) & 511;
+            int base = iabs(t - 256); if (base > 255) base = 255;
+            int v = ((base * 3) >> 2) + 32 + ((i ^ j) & 15) + int(xs & 7) + int((xs >> 3) & 7) - 7;
+            img[size_t(i) * size_t(w) + size_t(j)] = uint8_t(iclip(v, 0, 255));
+        }
+}
+
 const char *nblic_amd_version(void) { return "nblic_amd 0.1 (NBLIC v0.3 bitstream, gfx950)"; }
 
 nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders) {
@@ -380,7 +395,7 @@ void nblic_amd_set_max_pixels(nblic_amd_ctx *c, long max_pixels) { c->max_px = m
 void nblic_amd_enable_timing(nblic_amd_ctx *c, int on) { c->timing = on != 0; }
 
 int nblic_amd_stage_times(nblic_amd_ctx *c, double *ms, const char **names, int cap) {
-    int n = kE1Marks - 1;
+    int n = kE1Kernels;
     for (int k = 0; k < n && k < cap; k++) { ms[k] = c->stage_ms[k]; if (names) names[k] = kE1StageNames[k]; }
     return n < cap ? n : cap;
 }
