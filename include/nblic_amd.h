@@ -96,6 +96,10 @@ void nblic_amd_last_stats(nblic_amd_ctx *ctx, double *total_bins, double *coder_
 long nblic_amd_debug_stage(nblic_amd_ctx *ctx, const unsigned char *img, int height, int width, int which,
                            void *out, size_t out_bytes);
 
+/* Device self-test of the wave primitives the chain kernels rely on (DPP prefix sum against the
+ * shuffle formulation).  Returns the number of mismatching lanes (0 = pass) or -1.           */
+int nblic_amd_selftest(nblic_amd_ctx *ctx);
+
 /* The host half of the path on its own: the serial range-coder stage (src/NBLIC.c:552-586) over
  * n coded bins (u16 each: probability of a 1 in 1/4096 in bits 0-11, the bin in bit 15).
  * Writes at most cap bytes (coder bytes + 4 flush bytes, no header); returns the byte count or

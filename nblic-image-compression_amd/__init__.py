@@ -33,7 +33,7 @@ EXPORTS = (
     "NBLICcompress", "NBLICdecompress", "QNBLICcompress", "QNBLICdecompress", "QNBLICcompressMultiThread",
     "nblic_amd_create", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_set_max_pixels",
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_stats", "nblic_amd_debug_stage",
-    "nblic_amd_range_code", "nblic_amd_syn1", "nblic_amd_version",
+    "nblic_amd_range_code", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
 )
 
 
@@ -88,6 +88,8 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_debug_stage.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.nblic_amd_range_code.restype = C.c_size_t
     lib.nblic_amd_range_code.argtypes = [C.POINTER(C.c_uint16), C.c_size_t, _u8p, C.c_size_t]
+    lib.nblic_amd_selftest.restype = C.c_int
+    lib.nblic_amd_selftest.argtypes = [C.c_void_p]
     lib.nblic_amd_syn1.restype = None
     lib.nblic_amd_syn1.argtypes = [_u8p, C.c_int, C.c_int, C.c_uint32]
     lib.nblic_amd_version.restype = C.c_char_p
@@ -179,6 +181,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def selftest(self) -> int:
+        return self.lib.nblic_amd_selftest(self.handle)
 
     def enable_timing(self, on: bool = True):
         self.lib.nblic_amd_enable_timing(self.handle, int(on))

@@ -51,6 +51,7 @@ static const char *const kE1StageNames[kE1Kernels] = {
     "k_counter_chains",
     "k_mix"};
 
+int e1_selftest(hipStream_t s);     // 0 = DPP wave scan agrees with the shuffle scan
 void e1_init_state(const E1Buffers &b, hipStream_t s);
 void e1_launch_front(const E1Buffers &b, int h, int w, hipStream_t s, E1Timers *tm);
 void e1_launch_back(const E1Buffers &b, int h, int w, uint32_t n_ev, hipStream_t s, E1Timers *tm);

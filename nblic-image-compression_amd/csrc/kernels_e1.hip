@@ -52,6 +52,42 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
+// Same prefix sum on the DPP crossbar (no LDS round trips): Kogge-Stone inside each 16-lane
+// row with row_shr, then row_bcast:15 into rows 1/3 and row_bcast:31 into rows 2/3.
+__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v) {
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, true));    // row_shr:1
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, true));    // row_shr:2
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, true));    // row_shr:4
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, true));    // row_shr:8
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); }
+
+// Stages, for each of the wave's 64 private streams, the next <= 64 records into LDS with
+// COALESCED global reads: for source lane l the whole wave reads stream l's next run
+// (one contiguous <= 512 B / 256 B request), then every lane consumes its own row.  Rows are
+// padded to 65 records so the column reads of the consume loop are bank-conflict free.
+constexpr int kStageRow = 65;
+
+template <class Rec>
+__device__ __forceinline__ void stage_streams(const Rec *__restrict__ src, Rec *stage, uint32_t r, uint32_t rem, uint64_t active) {
+    const int lane = lane_id();
+    for (int l0 = 0; l0 < 64; l0 += 8) {
+        if (((active >> l0) & 0xFFull) == 0ull) continue;                       // wave-uniform
+        Rec tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            uint32_t base = read_lane(r, l0 + u), cnt = min(read_lane(rem, l0 + u), 64u);
+            if (uint32_t(lane) < cnt) tmp[u] = src[base + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) stage[(l0 + u) * kStageRow + lane] = tmp[u];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // S1: predictor, activity level, context address.  NBLIC.c:287-410.
 // grid = (ceil(w/256), h); one lane per pixel.  err_prev (the clipped error of the pixel to
@@ -131,20 +167,31 @@ __global__ void __launch_bounds__(256) k_adr_scatter(const uint32_t *__restrict_
 __global__ void __launch_bounds__(64) k_bias_chains(const uint2 *__restrict__ s2rec, const uint32_t *__restrict__ table,
                                                     SegPlan plan, uint32_t n, int *__restrict__ ctx_state,
                                                     uint16_t *__restrict__ pxs) {
-    int key = int(blockIdx.x) * 64 + int(threadIdx.x);
+    __shared__ uint2 stage[64 * kStageRow];
+    const int lane = int(threadIdx.x);
+    const int key = int(blockIdx.x) * 64 + lane;
     uint32_t r = table[size_t(key) * plan.nseg];
-    uint32_t end = key + 1 < kContexts ? table[size_t(key + 1) * plan.nseg] : n;
+    const uint32_t end = key + 1 < kContexts ? table[size_t(key + 1) * plan.nseg] : n;
     int v = ctx_state[key];
-    if (r < end) {
-        uint2 cur = s2rec[r];
-        while (r < end) {
-            uint2 nxt = (r + 1 < end) ? s2rec[r + 1] : cur;      // independent of the state: prefetch
-            int px0 = int(cur.y & 0xFF);
-            int err = int(int8_t(cur.y >> 8));
-            pxs[cur.x] = uint16_t(bias_apply(v, px0) | (bias_sign(v) << 8));
-            v = bias_update(v, err);
-            cur = nxt; r++;
+    for (;;) {
+        uint32_t rem = end - r;
+        uint64_t active = __ballot(rem > 0u);
+        if (active == 0ull) break;
+        stage_streams(s2rec, stage, r, rem, active);
+        __syncthreads();
+        const int mine = int(min(rem, 64u));
+        for (int i = 0; i < 64; i++) {
+            if (__ballot(i < mine) == 0ull) break;
+            if (i < mine) {
+                uint2 cur = stage[lane * kStageRow + i];
+                int px0 = int(cur.y & 0xFF);
+                int err = int(int8_t(cur.y >> 8));
+                pxs[cur.x] = uint16_t(bias_apply(v, px0) | (bias_sign(v) << 8));
+                v = bias_update(v, err);
+            }
         }
+        r += uint32_t(mine);
+        __syncthreads();
     }
     ctx_state[key] = v;
 }
@@ -203,6 +250,7 @@ __global__ void __launch_bounds__(64) k_mapper_chains(const uint32_t *__restrict
                                                       SegPlan plan, uint32_t n_items_total_dummy, const uint32_t *__restrict__ total,
                                                       int *__restrict__ map_state, uint8_t *__restrict__ z) {
     __shared__ int rank_of[kMapSyms][64], sym_at[kMapSyms][64], count[kMapSyms][64];
+    __shared__ uint32_t stage[64 * kStageRow];
     const int lane = int(threadIdx.x);
     const int key = int(blockIdx.x) * 64 + lane;
     int *st = map_state + size_t(key) * (3 * kMapSyms);
@@ -210,28 +258,37 @@ __global__ void __launch_bounds__(64) k_mapper_chains(const uint32_t *__restrict
         rank_of[k][lane] = st[k]; sym_at[k][lane] = st[kMapSyms + k]; count[k][lane] = st[2 * kMapSyms + k];
     }
     uint32_t r = table[size_t(key) * plan.nseg];
-    uint32_t end = key + 1 < 512 ? table[size_t(key + 1) * plan.nseg] : *total;
+    const uint32_t end = key + 1 < 512 ? table[size_t(key + 1) * plan.nseg] : *total;
     (void)n_items_total_dummy;
-    if (r < end) {
-        uint32_t cur = s3rec[r];
-        while (r < end) {
-            uint32_t nxt = (r + 1 < end) ? s3rec[r + 1] : cur;
-            int y = int(cur >> 27);
-            int zz = rank_of[y][lane];
-            z[cur & 0x7FFFFFFu] = uint8_t(zz);
-            int c = count[zz][lane] + 1;
-            count[zz][lane] = c;
-            if (zz > 0) {
-                int c_up = count[zz - 1][lane];
-                if (c_up < c) {                                   // overtake the rank above
-                    int other = sym_at[zz - 1][lane];
-                    count[zz][lane] = c_up;  count[zz - 1][lane] = c;
-                    sym_at[zz][lane] = other; sym_at[zz - 1][lane] = y;
-                    rank_of[y][lane] = zz - 1; rank_of[other][lane] = zz;
+    for (;;) {
+        uint32_t rem = end - r;
+        uint64_t active = __ballot(rem > 0u);
+        if (active == 0ull) break;
+        stage_streams(s3rec, stage, r, rem, active);
+        __syncthreads();
+        const int mine = int(min(rem, 64u));
+        for (int i = 0; i < 64; i++) {
+            if (__ballot(i < mine) == 0ull) break;
+            if (i < mine) {
+                uint32_t cur = stage[lane * kStageRow + i];
+                int y = int(cur >> 27);
+                int zz = rank_of[y][lane];
+                z[cur & 0x7FFFFFFu] = uint8_t(zz);
+                int c = count[zz][lane] + 1;
+                count[zz][lane] = c;
+                if (zz > 0) {
+                    int c_up = count[zz - 1][lane];
+                    if (c_up < c) {                               // overtake the rank above
+                        int other = sym_at[zz - 1][lane];
+                        count[zz][lane] = c_up;  count[zz - 1][lane] = c;
+                        sym_at[zz][lane] = other; sym_at[zz - 1][lane] = y;
+                        rank_of[y][lane] = zz - 1; rank_of[other][lane] = zz;
+                    }
                 }
             }
-            cur = nxt; r++;
         }
+        r += uint32_t(mine);
+        __syncthreads();
     }
     for (int k = 0; k < kMapSyms; k++) {
         st[k] = rank_of[k][lane]; st[kMapSyms + k] = sym_at[k][lane]; st[2 * kMapSyms + k] = count[k][lane];
@@ -334,51 +391,95 @@ __global__ void __launch_bounds__(256) k_touch_scatter(const uint32_t *__restric
 
 // ---- S5: counter chains, one wave per counter (NBLIC.c:589-637) ---------------------------
 // Between two halvings a counter is a pure running sum, and a halving needs the sum to climb
-// from <= 4113 past 8192 in steps <= 32, i.e. >= 128 touches: a 64-touch chunk holds at most
-// one.  So each chunk is one wave prefix sum plus (rarely) one exact halving fix-up.
+// from <= 4129 past 8192 in steps <= 32, i.e. >= 127 touches.  Each iteration takes 256 touches
+// (4 consecutive ones per lane, read as two 16-byte loads, next chunk prefetched), prefix-sums
+// the weights on the DPP crossbar, and then resolves the (at most three) halvings that fall in
+// the chunk one epoch at a time; every other touch is plain arithmetic on its prefix.
+struct TouchQuad { uint32_t ev[4]; uint32_t pay[4]; };
+
+__device__ __forceinline__ TouchQuad load_quad(const uint2 *__restrict__ touch, uint32_t first, uint32_t end) {
+    TouchQuad q;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint2 t = (first + k < end) ? touch[first + k] : make_uint2(0u, 0u);
+        q.ev[k] = t.x; q.pay[k] = t.y;
+    }
+    return q;
+}
+
 __global__ void __launch_bounds__(64) k_counter_chains(const uint2 *__restrict__ touch, const uint32_t *__restrict__ table,
                                                        SegPlan plan, const uint32_t *__restrict__ total,
                                                        int2 *__restrict__ cnt_state, uint16_t *__restrict__ puv) {
     const int key = int(blockIdx.x);
     const int lane = int(threadIdx.x);
-    uint32_t start = table[size_t(key) * plan.nseg];
-    uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * plan.nseg] : *total;
+    const uint32_t start = table[size_t(key) * plan.nseg];
+    const uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * plan.nseg] : *total;
     if (start >= end) return;
     int2 st = cnt_state[key];
-    int c0 = st.x, c1 = st.y;                                       // wave-uniform
-    for (uint32_t base = start; base < end; base += 64) {
-        uint32_t r = base + lane;
-        bool valid = r < end;
-        uint2 tr = valid ? touch[r] : make_uint2(0u, 0u);
-        int w1 = int(tr.y & 63), w2 = int((tr.y >> 6) & 63), bin = int((tr.y >> 12) & 1);
-        int slot = int((tr.y >> 13) & 1), dbl = int((tr.y >> 14) & 1);
-        int tot = w1 + w2, one = bin ? tot : 0;
-        uint32_t incl = wave_scan_incl((uint32_t(tot) << 16) | uint32_t(one));
-        int T = int(incl >> 16), O = int(incl & 0xFFFF);            // inclusive sums
-        int s_pre = c0 + c1 + T - tot, c1_pre = c1 + O - one;
-        // first lane whose touch pushes the sum over the limit
-        uint64_t over = __ballot(valid && (s_pre + tot > kCountLimit));
-        int T_end = __shfl(T, 63, 64), O_end = __shfl(O, 63, 64);
-        if (over == 0ull) {
-            c1 += O_end; c0 += T_end - O_end;
-        } else {
-            int H = __ffsll((unsigned long long)over) - 1;          // uniform
-            int hs = __shfl(s_pre, H, 64), h1 = __shfl(c1_pre, H, 64);
-            int hw1 = __shfl(w1, H, 64), hw2 = __shfl(w2, H, 64), hb = __shfl(bin, H, 64);
-            int hT = __shfl(T, H, 64), hO = __shfl(O, H, 64);
-            Counter c{hs - h1, h1};
-            counter_add(c, hb, hw1);
-            if (hw2) counter_add(c, hb, hw2);                       // state after lane H, halving applied where it fell
-            if (lane > H) { c1_pre = c.c1 + (O - one) - hO; s_pre = c.c0 + c.c1 + (T - tot) - hT; }
-            c1 = c.c1 + O_end - hO; c0 = c.c0 + (T_end - hT) - (O_end - hO);
+    int base_s = st.x + st.y, base_1 = st.y;                         // wave-uniform running state
+    TouchQuad nxt = load_quad(touch, start + uint32_t(lane) * 4u, end);
+    for (uint32_t chunk = start; chunk < end; chunk += 256u) {
+        const TouchQuad q = nxt;
+        const uint32_t first = chunk + uint32_t(lane) * 4u;
+        if (chunk + 256u < end) nxt = load_quad(touch, first + 256u, end);
+        int tot[4], one[4], tex[4], oex[4];
+        int lt = 0, lo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int w = int(q.pay[k] & 63) + int((q.pay[k] >> 6) & 63);
+            tot[k] = (first + k < end) ? w : 0;
+            one[k] = ((q.pay[k] >> 12) & 1) ? tot[k] : 0;
+            tex[k] = lt; oex[k] = lo; lt += tot[k]; lo += one[k];
         }
-        if (valid) {
-            uint16_t p = uint16_t(counter_p1(s_pre - c1_pre, c1_pre));
-            size_t o = size_t(tr.x) * 2;
-            if (dbl) { puv[o] = p; puv[o + 1] = p; } else puv[o + slot] = p;
+        uint32_t incl = wave_scan_incl_dpp((uint32_t(lt) << 16) | uint32_t(lo));
+        const int lane_t = int(incl >> 16) - lt, lane_o = int(incl & 0xFFFF) - lo;    // exclusive over lanes
+        const int chunk_t = int(read_lane(incl, 63) >> 16), chunk_o = int(read_lane(incl, 63) & 0xFFFF);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { tex[k] += lane_t; oex[k] += lane_o; }
+        // virtual base: state before touch j of the current epoch = vb + exclusive prefix(j)
+        int vb_s = base_s, vb_1 = base_1;
+        int from = 0;                                               // first touch (chunk-relative) of the epoch
+        int s_pre[4], c1_pre[4];
+        for (;;) {
+            int trig = 4;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                int j = lane * 4 + k;
+                if (j >= from) {
+                    s_pre[k] = vb_s + tex[k]; c1_pre[k] = vb_1 + oex[k];
+                    if (s_pre[k] + tot[k] > kCountLimit) trig = k;
+                }
+            }
+            uint64_t over = __ballot(trig < 4);
+            if (over == 0ull) break;
+            const int H = __ffsll((unsigned long long)over) - 1;    // first lane with a halving, uniform
+            const int hk = int(read_lane(uint32_t(trig), H));
+            int sel_s = s_pre[0], sel_1 = c1_pre[0], sel_tex = tex[0], sel_oex = oex[0], sel_tot = tot[0], sel_one = one[0];
+            uint32_t sel_pay = q.pay[0];
+#pragma unroll
+            for (int k = 1; k < 4; k++)
+                if (hk == k) { sel_s = s_pre[k]; sel_1 = c1_pre[k]; sel_tex = tex[k]; sel_oex = oex[k]; sel_tot = tot[k]; sel_one = one[k]; sel_pay = q.pay[k]; }
+            const int hs = int(read_lane(uint32_t(sel_s), H)), h1 = int(read_lane(uint32_t(sel_1), H));
+            const uint32_t hp = read_lane(sel_pay, H);
+            const int h_tin = int(read_lane(uint32_t(sel_tex + sel_tot), H)), h_oin = int(read_lane(uint32_t(sel_oex + sel_one), H));
+            Counter c{hs - h1, h1};
+            const int hb = int((hp >> 12) & 1), hw1 = int(hp & 63), hw2 = int((hp >> 6) & 63);
+            counter_add(c, hb, hw1);
+            if (hw2) counter_add(c, hb, hw2);                       // state after the triggering touch
+            vb_s = c.c0 + c.c1 - h_tin; vb_1 = c.c1 - h_oin;
+            from = H * 4 + hk + 1;
+        }
+        base_s = vb_s + chunk_t; base_1 = vb_1 + chunk_o;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (first + k < end) {
+                uint16_t p = uint16_t(counter_p1(s_pre[k] - c1_pre[k], c1_pre[k]));
+                size_t o = size_t(q.ev[k]) * 2;
+                if ((q.pay[k] >> 14) & 1) { puv[o] = p; puv[o + 1] = p; } else puv[o + ((q.pay[k] >> 13) & 1)] = p;
+            }
         }
     }
-    if (lane == 0) cnt_state[key] = make_int2(c0, c1);
+    if (lane == 0) cnt_state[key] = make_int2(base_s - base_1, base_1);
 }
 
 // ---- mix the two trees' probabilities and pack for the host coder (NBLIC.c:629-633) -------
@@ -453,6 +554,26 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const T *in, uint32
     uint32_t pre = sums[blockIdx.x] + incl - s;
     for (int wv = 0; wv < int(threadIdx.x >> 6); wv++) pre += part[wv];
     for (int k = 0; k < kScanPerThread; k++) { if (base + k < n) out[base + k] = pre; pre += v[k]; }
+}
+
+// self-test: the DPP scan must equal the shuffle scan on arbitrary data
+__global__ void k_selftest_scan(const uint32_t *in, uint32_t *bad) {
+    uint32_t v = in[blockIdx.x * 64 + threadIdx.x];
+    if (wave_scan_incl(v) != wave_scan_incl_dpp(v)) atomicAdd(bad, 1u);
+}
+
+int e1_selftest(hipStream_t s) {
+    uint32_t host[64 * 64], *d_in = nullptr, *d_bad = nullptr, bad = 1;
+    uint32_t x = 12345u;
+    for (auto &h : host) { x = x * 1664525u + 1013904223u; h = x >> 8; }
+    if (hipMalloc((void **)&d_in, sizeof host) != hipSuccess || hipMalloc((void **)&d_bad, 4) != hipSuccess) return -1;
+    hipMemcpyAsync(d_in, host, sizeof host, hipMemcpyHostToDevice, s);
+    hipMemsetAsync(d_bad, 0, 4, s);
+    hipLaunchKernelGGL(k_selftest_scan, dim3(64), dim3(64), 0, s, d_in, d_bad);
+    hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    hipFree(d_in); hipFree(d_bad);
+    return int(bad);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -344,6 +344,11 @@ size_t nblic_amd_range_code(const uint16_t *coded, size_t n, unsigned char *out,
     return range_code(coded, n, out, cap);
 }
 
+int nblic_amd_selftest(nblic_amd_ctx *c) {
+    if (!c || hipSetDevice(c->device) != hipSuccess) return -1;
+    return e1_selftest(c->slots[0].stream);
+}
+
 void nblic_amd_syn1(unsigned char *img, int h, int w, uint32_t seed) {
     uint32_t xs = seed;
     for (int i = 0; i < h; i++)

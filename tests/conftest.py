@@ -48,6 +48,13 @@ def golden():
 
 @pytest.fixture(scope="session")
 def gpu_ctx(pkg):
+    # PyTorch-ROCm bundles its own HIP runtime: when both live in one process torch must
+    # initialise first so the library binds to the runtime that is already loaded.
+    try:
+        import torch
+        torch.cuda.init()
+    except Exception:
+        pass
     ctx = pkg.Context(device=0, n_slots=3, n_coders=3)
     yield ctx
     ctx.close()

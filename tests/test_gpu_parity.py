@@ -25,6 +25,10 @@ def unpack_rec1(r):
     return px0, adr, qu, qv, qw
 
 
+def test_wave_primitives_selftest(gpu_ctx):
+    assert gpu_ctx.selftest() == 0
+
+
 STAGE_SHAPES = [(1, 1), (1, 9), (9, 1), (2, 2), (3, 5), (17, 13), (40, 37), (64, 64), (96, 128), (5, 300)]
 
 
