@@ -63,6 +63,11 @@ typedef struct nblic_amd_ctx nblic_amd_ctx;
  * n_coders : host threads running the serial range-coder stage; >= 1.
  * returns NULL (and prints why) when the device cannot be used.                            */
 nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders);
+
+/* Same, with the split of the images in flight spelled out: n_groups groups of group_size
+ * images.  A group shares every kernel launch (its serial chains run side by side); while the
+ * host codes one group the GPU works on the next.  nblic_amd_create uses two groups.          */
+nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int n_coders);
 void nblic_amd_destroy(nblic_amd_ctx *ctx);
 
 /* Encode n_images gray planes at -n0 -e1 (lossless) into byte-exact .nblic streams.
@@ -80,12 +85,16 @@ int nblic_amd_encode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned char
 void nblic_amd_set_max_pixels(nblic_amd_ctx *ctx, long max_pixels);
 
 /* Per-kernel device times of the LAST nblic_amd_encode_batch: one HIP event in front of every
- * launch, on the stream the kernel runs on, summed over the batch's images (divide by the
- * image count for the average launch duration).  Writes up to `cap` entries
+ * launch, on the stream the kernel runs on, summed over the batch's group launches (divide by
+ * nblic_amd_last_launches() for the average launch duration).  Writes up to `cap` entries
  * of milliseconds into ms[] and matching static strings into names[]; returns the count.
  * Timing is recorded only after nblic_amd_enable_timing(ctx, 1).                           */
 void nblic_amd_enable_timing(nblic_amd_ctx *ctx, int on);
 int nblic_amd_stage_times(nblic_amd_ctx *ctx, double *ms, const char **names, int cap);
+
+/* How many group launches the last batch took (each kernel of the sequence is launched once
+ * per group of images); the entries of nblic_amd_stage_times() are sums over these launches. */
+long nblic_amd_last_launches(nblic_amd_ctx *ctx);
 
 /* Bins coded / host range-coder seconds summed over the last batch (for reporting). */
 void nblic_amd_last_stats(nblic_amd_ctx *ctx, double *total_bins, double *coder_seconds_sum);

@@ -31,8 +31,8 @@ _lib = None
 # every symbol include/nblic_amd.h declares
 EXPORTS = (
     "NBLICcompress", "NBLICdecompress", "QNBLICcompress", "QNBLICdecompress", "QNBLICcompressMultiThread",
-    "nblic_amd_create", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_set_max_pixels",
-    "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_stats", "nblic_amd_debug_stage",
+    "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_set_max_pixels",
+    "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
     "nblic_amd_range_code", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
 )
 
@@ -71,6 +71,8 @@ def load_library() -> C.CDLL:
     lib.QNBLICdecompress.argtypes = [u16p, _u8p, ip, ip]
     lib.nblic_amd_create.restype = C.c_void_p
     lib.nblic_amd_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.nblic_amd_create_ex.restype = C.c_void_p
+    lib.nblic_amd_create_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.nblic_amd_destroy.restype = None
     lib.nblic_amd_destroy.argtypes = [C.c_void_p]
     lib.nblic_amd_encode_batch.restype = C.c_int
@@ -82,6 +84,8 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.nblic_amd_stage_times.restype = C.c_int
     lib.nblic_amd_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.c_int]
+    lib.nblic_amd_last_launches.restype = C.c_long
+    lib.nblic_amd_last_launches.argtypes = [C.c_void_p]
     lib.nblic_amd_last_stats.restype = None
     lib.nblic_amd_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.nblic_amd_debug_stage.restype = C.c_long
@@ -164,9 +168,12 @@ def range_code(coded: np.ndarray, cap: Optional[int] = None) -> Optional[bytes]:
 class Context:
     """Several images in flight on one GPU (``nblic_amd_create``)."""
 
-    def __init__(self, device: int = 0, n_slots: int = 4, n_coders: int = 4):
+    def __init__(self, device: int = 0, n_slots: int = 4, n_coders: int = 4, n_groups: int = 0):
         self.lib = load_library()
-        self.handle = self.lib.nblic_amd_create(device, n_slots, n_coders)
+        if n_groups > 0:
+            self.handle = self.lib.nblic_amd_create_ex(device, n_groups, (n_slots + n_groups - 1) // n_groups, n_coders)
+        else:
+            self.handle = self.lib.nblic_amd_create(device, n_slots, n_coders)
         if not self.handle:
             raise RuntimeError("nblic_amd_create failed: no usable HIP device (the hot path has no CPU fallback)")
         self.device, self.n_slots, self.n_coders = device, n_slots, n_coders
@@ -220,6 +227,9 @@ class Context:
         names = (C.c_char_p * 64)()
         n = self.lib.nblic_amd_stage_times(self.handle, ms, names, 64)
         return {names[i].decode(): ms[i] for i in range(n)}
+
+    def last_launches(self) -> int:
+        return int(self.lib.nblic_amd_last_launches(self.handle))
 
     def last_stats(self) -> Tuple[float, float]:
         b, s = C.c_double(), C.c_double()

@@ -12,13 +12,19 @@ SegPlan make_plan(uint32_t n_items);
 
 // Device buffers of one image in flight.  Pixel-sized arrays hold n = h*w entries,
 // event-sized arrays hold ev_cap entries.
+constexpr size_t kStreamPad = 512;         // u16 records of slack after every key-sorted stream
+
 struct E1Buffers {
     const uint8_t *img;      // n      input plane (lossless: also the reconstruction)
     uint32_t *rec1;          // n      S1 record (model.h pack_s1)
-    uint64_t *s2rec;         // n      {t, px0|err<<8} grouped by context
-    uint16_t *pxs;           // n      px | sign<<8
-    uint32_t *s3rec;         // n      t | y<<27 grouped by re-mapper
-    uint8_t  *z;             // n      coded symbol
+    uint16_t *s2in;          // n+pad  px0 | err<<8, grouped by context
+    uint32_t *pos2;          // n      where pixel t sits in s2in / s2out
+    uint16_t *s2out;         // n+pad  px | sign<<8, same order as s2in
+    uint16_t *pxs;           // n      px | sign<<8 back in raster order
+    uint16_t *s3in;          // n+pad  y (< 20), grouped by re-mapper
+    uint32_t *pos3;          // n      where pixel t sits in s3in / s3out, or 0x80000000 | y (bypass)
+    uint16_t *s3out;         // n+pad  z, same order as s3in
+    uint8_t  *z;             // n      coded symbol, raster order
     uint8_t  *cnt;           // n      bins per pixel
     uint32_t *ev_off;        // n      exclusive scan of cnt
     uint32_t *table;         // 4096 * kMaxSegments   partition histogram / offsets
@@ -27,19 +33,32 @@ struct E1Buffers {
     int      *ctx_state;     // 2048
     int      *map_state;     // 512 * 60
     int      *cnt_state;     // 4096 * 2
-    uint32_t *events;        // ev_cap
-    uint64_t *touch;         // 2 * ev_cap
-    uint16_t *puv;           // 2 * ev_cap
-    uint16_t *coded;         // ev_cap   prob | bin<<15 for the host range coder
+    uint32_t *events;        // ev_cap        model.h pack_event
+    uint16_t *tin;           // 2*ev_cap+pad  touch payloads grouped by counter
+    uint64_t *tpos;          // ev_cap        {position of the tree-u touch, of the tree-v touch}
+    uint16_t *tout;          // 2*ev_cap+pad  P(bin==1) before each touch, same order as tin
+    uint16_t *coded;         // ev_cap        prob | bin<<15 for the host range coder
+};
+
+// One image of a group.  The array of jobs lives in device memory; every kernel picks its job
+// from the last grid dimension.
+struct E1Job {
+    E1Buffers b;
+    int h, w;
+    uint32_t n;          // h * w
+    SegPlan pp;          // partition plan over pixels
+    uint32_t n_ev;       // bins (known after the front half)
+    SegPlan pe;          // partition plan over bins
 };
 
 // One HIP event before every kernel launch (and one after the last): interval k is exactly
-// kernel k of the launch sequence below, measured on the stream it runs on.
-constexpr int kE1Kernels = 26;
+// launch k of the sequence below, measured on the stream it runs on.  A launch covers the
+// whole group of images.
+constexpr int kE1Kernels = 27;
 constexpr int kE1Marks = kE1Kernels + 1;
 struct E1Timers { hipEvent_t ev[kE1Marks]; };
 static const char *const kE1StageNames[kE1Kernels] = {
-    "k_predict",
+    "k_init_state", "k_predict",
     "k_adr_count", "scan_reduce.adr", "scan_sums.adr", "scan_apply.adr", "k_adr_scatter",
     "k_bias_chains",
     "k_map_count", "scan_reduce.map", "scan_sums.map", "scan_apply.map", "k_map_scatter",
@@ -52,8 +71,8 @@ static const char *const kE1StageNames[kE1Kernels] = {
     "k_mix"};
 
 int e1_selftest(hipStream_t s);     // 0 = DPP wave scan agrees with the shuffle scan
-void e1_init_state(const E1Buffers &b, hipStream_t s);
-void e1_launch_front(const E1Buffers &b, int h, int w, hipStream_t s, E1Timers *tm);
-void e1_launch_back(const E1Buffers &b, int h, int w, uint32_t n_ev, hipStream_t s, E1Timers *tm);
+// d_jobs: device copy of h_jobs[0..n_jobs).  The host copy is only read to size the grids.
+void e1_launch_front(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm);
+void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm);
 
 }  // namespace nblic

@@ -6,17 +6,23 @@
 // at a time over a stable (raster-order-preserving) partition of the work items:
 //
 //   k_predict            S1  stateless, one lane per pixel        -> rec1[t]
-//   partition by adr     (count -> scan -> scatter)               -> s2rec[]  grouped by context
-//   k_bias_chains        S2  one LANE per context chain           -> pxs[t] = px | sign<<8
-//   partition by px|sign                                          -> s3rec[]  grouped by re-mapper
-//   k_mapper_chains      S3  one LANE per re-mapper chain, state in LDS -> z[t]
-//   k_count_bins/k_emit_bins  S4 stateless                        -> events[r]
-//   partition by counter (even / odd trees)                       -> touch[]  grouped by counter
-//   k_counter_chains     S5  one WAVE per counter chain (scan within a halving epoch)
-//   k_mix                probability mix + pack                   -> coded[r] (u16) for the host coder
+//   partition by adr     (count -> scan -> scatter)               -> s2in[]  grouped by context, pos2[t]
+//   k_bias_chains        S2  one LANE per context chain           -> s2out[] (px | sign<<8, same order)
+//   partition by px|sign (gathers s2out through pos2)             -> s3in[]  grouped by re-mapper, pos3[t]
+//   k_mapper_chains      S3  one LANE per re-mapper chain, state in LDS -> s3out[] (z, same order)
+//   k_count_bins/k_emit_bins  S4 stateless (gathers z through pos3)     -> events[r]
+//   partition by counter (even / odd trees)                       -> tin[]  grouped by counter, tpos[2r+slot]
+//   k_counter_chains     S5  one WAVE per counter chain (scan within a halving epoch) -> tout[] (P, same order)
+//   k_mix                gathers the two P through tpos, mixes, packs -> coded[r] (u16) for the host coder
 //
-// Wave64 throughout; no MFMA (nothing here is a contraction).  All kernels take one image;
-// the host pipeline runs several images concurrently on separate HIP streams.
+// The chain kernels are the serial part, so they touch memory only as dense streams of 2-byte
+// records in key-sorted order: every global request of a chain kernel is one coalesced 512-byte
+// line run staged through LDS.  The scatter/gather between raster order and key order is done
+// by the surrounding full-occupancy passes, which hide its latency behind thousands of waves.
+//
+// Wave64 throughout; no MFMA (nothing here is a contraction).  Every launch covers a GROUP of
+// images (E1Job array in device memory, job = last grid dimension), so the serial chains of
+// many images run side by side on different CUs by construction.
 #include <hip/hip_runtime.h>
 #include "model.h"
 #include "kernels_e1.h"
@@ -64,27 +70,81 @@ __device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v) {
     return v;
 }
 
+// P(bin==1) = floor(4096 * c1 / (c0 + c1)) without the integer-divide expansion: c1 and the sum
+// are < 2^14, so 4096*c1 and the sum are exact floats, the reciprocal estimate is off by far
+// less than one, and one remainder check makes the quotient exact.
+__device__ __forceinline__ uint32_t prob_one(int c1, int sum) {
+    int n = c1 << 12;
+    int q = int(float(n) * __builtin_amdgcn_rcpf(float(sum)));
+    int r = n - q * sum;
+    q += (r >= sum) - (r < 0);
+    return uint32_t(q);
+}
+
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); }
 
-// Stages, for each of the wave's 64 private streams, the next <= 64 records into LDS with
-// COALESCED global reads: for source lane l the whole wave reads stream l's next run
-// (one contiguous <= 512 B / 256 B request), then every lane consumes its own row.  Rows are
-// padded to 65 records so the column reads of the consume loop are bank-conflict free.
-constexpr int kStageRow = 65;
+// Lane-per-key streaming: each of the wave's 64 lanes owns one run of 2-byte records
+// in[r .. end) and must replace every record by step(record) in order.  Per round the wave
+// stages, for each live stream, the aligned 512-byte window that holds its next records with
+// ONE coalesced request (64 lanes x 8 B of the same stream), every lane then walks its own LDS
+// row in place, and the windows are written back the same way.  Rows are padded to 65 words so
+// the walk (all lanes on the same column of different rows) is bank-conflict free.
+// Arrays must be padded by 512 B: a window may extend past the last record.
+constexpr int kRowWords = 65;
 
-template <class Rec>
-__device__ __forceinline__ void stage_streams(const Rec *__restrict__ src, Rec *stage, uint32_t r, uint32_t rem, uint64_t active) {
+template <class StepFn>
+__device__ __forceinline__ void run_lane_streams(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, uint32_t r,
+                                                 const uint32_t end, uint2 *stage, StepFn step) {
     const int lane = lane_id();
-    for (int l0 = 0; l0 < 64; l0 += 8) {
-        if (((active >> l0) & 0xFFull) == 0ull) continue;                       // wave-uniform
-        Rec tmp[8];
+    const uint2 *in_w = reinterpret_cast<const uint2 *>(in);
+    uint2 *out_w = reinterpret_cast<uint2 *>(out);
+    for (;;) {
+        const bool live = r < end;
+        const uint64_t active = __ballot(live);
+        if (active == 0ull) break;
+        const uint32_t base = r & ~3u;                       // window = records [base, base + 256)
+        const uint32_t stop = live ? min(end, base + 256u) : r;
+        for (int l0 = 0; l0 < 64; l0 += 8) {                 // ---- load windows
+            if (((active >> l0) & 0xFFull) == 0ull) continue;
+            uint2 tmp[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            uint32_t base = read_lane(r, l0 + u), cnt = min(read_lane(rem, l0 + u), 64u);
-            if (uint32_t(lane) < cnt) tmp[u] = src[base + lane];
+            for (int u = 0; u < 8; u++) tmp[u] = in_w[(read_lane(base, l0 + u) >> 2) + lane];
+#pragma unroll
+            for (int u = 0; u < 8; u++) stage[(l0 + u) * kRowWords + lane] = tmp[u];
         }
+        __syncthreads();
+        const int c0 = int(r - base), c1 = int(stop - base); // ---- walk own row: columns [c0, c1)
+        for (int wi = 0; wi < 64; wi++) {
+            const bool mine = live && wi * 4 + 3 >= c0 && wi * 4 < c1;
+            if (__ballot(mine) == 0ull) continue;
+            if (mine) {
+                uint2 w = stage[lane * kRowWords + wi];
+                uint32_t rec[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
 #pragma unroll
-        for (int u = 0; u < 8; u++) stage[(l0 + u) * kStageRow + lane] = tmp[u];
+                for (int k = 0; k < 4; k++) {
+                    const int col = wi * 4 + k;
+                    if (col >= c0 && col < c1) rec[k] = step(rec[k]) & 0xFFFFu;
+                }
+                stage[lane * kRowWords + wi] = make_uint2(rec[0] | (rec[1] << 16), rec[2] | (rec[3] << 16));
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < 64; l++) {                       // ---- write windows back
+            if (((active >> l) & 1ull) == 0ull) continue;
+            const uint32_t b = read_lane(base, l), lo = read_lane(r, l), hi = read_lane(stop, l);
+            const uint32_t idx = b + uint32_t(lane) * 4u;
+            if (idx + 4u <= lo || idx >= hi) continue;
+            const uint2 w = stage[l * kRowWords + lane];
+            if (idx >= lo && idx + 4u <= hi) {
+                out_w[idx >> 2] = w;
+            } else {                                         // window edge: only this stream's records
+                const uint32_t rec[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (idx + k >= lo && idx + k < hi) out[idx + k] = uint16_t(rec[k]);
+            }
+        }
+        r = stop;
+        __syncthreads();
     }
 }
 
@@ -94,11 +154,13 @@ __device__ __forceinline__ void stage_streams(const Rec *__restrict__ src, Rec *
 // the left, NBLIC.c:808/:878) is recomputed from the input image -- in lossless mode the
 // reconstruction IS the input, so S1 carries no state at all.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_predict(const uint8_t *__restrict__ img, int h, int w, int row0, int rows,
-                                                 uint32_t *__restrict__ rec1) {
+__global__ void __launch_bounds__(256) k_predict(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.z];
+    const int w = J.w;
     int j = int(blockIdx.x) * 256 + int(threadIdx.x);
-    int i = row0 + int(blockIdx.y);
-    if (j >= w) return;
+    int i = int(blockIdx.y);
+    if (i >= J.h || j >= w) return;
+    const uint8_t *__restrict__ img = J.b.img;
     auto pix = [&](int r, int c) { return int(img[size_t(r) * size_t(w) + size_t(c)]); };
     Taps n = sample_taps(pix, w, i, j);
     int px0 = predict(n);
@@ -108,7 +170,7 @@ __global__ void __launch_bounds__(256) k_predict(const uint8_t *__restrict__ img
         err_prev = clip_err(n.a, predict(m));
     }
     Level L = quantise(activity(n, err_prev));
-    rec1[size_t(blockIdx.y) * size_t(w) + size_t(j)] = pack_s1(px0, context_address(n, L.qu, px0), L);
+    J.b.rec1[size_t(i) * size_t(w) + size_t(j)] = pack_s1(px0, context_address(n, L.qu, px0), L);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -122,9 +184,11 @@ __device__ __forceinline__ void lds_fill(uint32_t *slice, uint32_t v) {
 }
 
 // ---- partition 1: pixels by context address (2048 keys) ----------------------------------
-__global__ void __launch_bounds__(256) k_adr_count(const uint32_t *__restrict__ rec1, uint32_t n, SegPlan plan,
-                                                   uint32_t *__restrict__ table) {
+__global__ void __launch_bounds__(256) k_adr_count(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][kContexts];
+    const E1Job &J = jobs[blockIdx.y];
+    const uint32_t *__restrict__ rec1 = J.b.rec1; uint32_t *__restrict__ table = J.b.table;
+    const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *hist = lds[threadIdx.x >> 6];
@@ -137,10 +201,12 @@ __global__ void __launch_bounds__(256) k_adr_count(const uint32_t *__restrict__ 
     for (int k = lane_id(); k < kContexts; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
 }
 
-__global__ void __launch_bounds__(256) k_adr_scatter(const uint32_t *__restrict__ rec1, const uint8_t *__restrict__ x,
-                                                     uint32_t n, SegPlan plan, const uint32_t *__restrict__ table,
-                                                     uint2 *__restrict__ s2rec) {
+__global__ void __launch_bounds__(256) k_adr_scatter(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][kContexts];
+    const E1Job &J = jobs[blockIdx.y];
+    const uint32_t *__restrict__ rec1 = J.b.rec1; const uint8_t *__restrict__ x = J.b.img;
+    const uint32_t *__restrict__ table = J.b.table; uint16_t *__restrict__ s2in = J.b.s2in; uint32_t *__restrict__ pos2 = J.b.pos2;
+    const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *off = lds[threadIdx.x >> 6];
@@ -155,59 +221,51 @@ __global__ void __launch_bounds__(256) k_adr_scatter(const uint32_t *__restrict_
         if (valid) {
             uint32_t rank = __popcll(same & lanes_below());
             uint32_t pos = off[key] + rank;
-            int px0 = s1_px0(r);
-            int err = clip_err(int(x[t]), px0);
-            s2rec[pos] = make_uint2(t, uint32_t(px0) | (uint32_t(err & 0xFF) << 8));
+            s2in[pos] = uint16_t(clip_err(int(x[t]), s1_px0(r)) & 0xFF);
+            pos2[t] = pos;
             if (rank == 0) off[key] += uint32_t(__popcll(same));
         }
     }
 }
 
 // ---- S2: context-bias chains, one lane per context (NBLIC.c:413-428) ---------------------
-__global__ void __launch_bounds__(64) k_bias_chains(const uint2 *__restrict__ s2rec, const uint32_t *__restrict__ table,
-                                                    SegPlan plan, uint32_t n, int *__restrict__ ctx_state,
-                                                    uint16_t *__restrict__ pxs) {
-    __shared__ uint2 stage[64 * kStageRow];
-    const int lane = int(threadIdx.x);
-    const int key = int(blockIdx.x) * 64 + lane;
-    uint32_t r = table[size_t(key) * plan.nseg];
+// The chain itself only needs the clipped error of each pixel and only has to publish the
+// state it held BEFORE that pixel: record in = err (low byte), record out = v >> 7, from which
+// the consumer rebuilds sign = out & 1 and px = clip(px0 + (out >> 1) + sign).
+__global__ void __launch_bounds__(64) k_bias_chains(const E1Job *__restrict__ jobs) {
+    __shared__ uint2 stage[64 * kRowWords];
+    const E1Job &J = jobs[blockIdx.y];
+    const uint16_t *__restrict__ s2in = J.b.s2in; const uint32_t *__restrict__ table = J.b.table;
+    int *__restrict__ ctx_state = J.b.ctx_state; uint16_t *__restrict__ s2out = J.b.s2out;
+    const uint32_t n = J.n; const SegPlan plan = J.pp;
+    const int key = int(blockIdx.x) * 64 + int(threadIdx.x);
+    const uint32_t start = table[size_t(key) * plan.nseg];
     const uint32_t end = key + 1 < kContexts ? table[size_t(key + 1) * plan.nseg] : n;
     int v = ctx_state[key];
-    for (;;) {
-        uint32_t rem = end - r;
-        uint64_t active = __ballot(rem > 0u);
-        if (active == 0ull) break;
-        stage_streams(s2rec, stage, r, rem, active);
-        __syncthreads();
-        const int mine = int(min(rem, 64u));
-        for (int i = 0; i < 64; i++) {
-            if (__ballot(i < mine) == 0ull) break;
-            if (i < mine) {
-                uint2 cur = stage[lane * kStageRow + i];
-                int px0 = int(cur.y & 0xFF);
-                int err = int(int8_t(cur.y >> 8));
-                pxs[cur.x] = uint16_t(bias_apply(v, px0) | (bias_sign(v) << 8));
-                v = bias_update(v, err);
-            }
-        }
-        r += uint32_t(mine);
-        __syncthreads();
-    }
+    run_lane_streams(s2in, s2out, start, end, stage, [&](uint32_t rec) {
+        uint32_t o = uint32_t(v >> (kCtxScale - 1));
+        v = bias_update(v, int(int8_t(rec)));
+        return o;
+    });
     ctx_state[key] = v;
 }
 
 // ---- partition 2: pixels by (px, sign) (512 keys); symbols >= 20 bypass the re-mapper -----
-__device__ __forceinline__ bool mapper_item(const uint8_t *x, const uint16_t *pxs, uint32_t t, uint32_t &key, int &y) {
-    uint32_t ps = pxs[t];
+// k_map_count also brings S2's output back to raster order (gather through pos2).
+__device__ __forceinline__ bool mapper_item(int x, uint32_t ps, uint32_t &key, int &y) {
     int px = int(ps & 0xFF), sign = int(ps >> 8);
-    y = residual_to_symbol(int(x[t]), px, sign, 0);
+    y = residual_to_symbol(x, px, sign, 0);
     key = uint32_t(px) * 2u + uint32_t(sign);
     return y < kMapSyms;
 }
 
-__global__ void __launch_bounds__(256) k_map_count(const uint8_t *__restrict__ x, const uint16_t *__restrict__ pxs, uint32_t n,
-                                                   SegPlan plan, uint32_t *__restrict__ table) {
+__global__ void __launch_bounds__(256) k_map_count(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][512];
+    const E1Job &J = jobs[blockIdx.y];
+    const uint8_t *__restrict__ x = J.b.img; const uint16_t *__restrict__ s2out = J.b.s2out;
+    const uint32_t *__restrict__ pos2 = J.b.pos2; uint16_t *__restrict__ pxs = J.b.pxs; uint32_t *__restrict__ table = J.b.table;
+    const uint32_t *__restrict__ rec1 = J.b.rec1;
+    const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *hist = lds[threadIdx.x >> 6];
@@ -215,15 +273,24 @@ __global__ void __launch_bounds__(256) k_map_count(const uint8_t *__restrict__ x
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t t = base + lane_id(), key; int y;
-        if (t < hi && mapper_item(x, pxs, t, key, y)) atomicAdd(&hist[key], 1u);
+        if (t < hi) {
+            int vs = int(int16_t(s2out[pos2[t]]));                     // context state >> 7 as the chain saw it
+            int sign = vs & 1;
+            uint16_t ps = uint16_t(iclip(s1_px0(rec1[t]) + (vs >> 1) + sign, 0, kMaxVal) | (sign << 8));
+            pxs[t] = ps;
+            if (mapper_item(int(x[t]), ps, key, y)) atomicAdd(&hist[key], 1u);
+        }
     }
     for (int k = lane_id(); k < 512; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
 }
 
-__global__ void __launch_bounds__(256) k_map_scatter(const uint8_t *__restrict__ x, const uint16_t *__restrict__ pxs, uint32_t n,
-                                                     SegPlan plan, const uint32_t *__restrict__ table,
-                                                     uint32_t *__restrict__ s3rec, uint8_t *__restrict__ z) {
+// pos3[t] = position of pixel t in s3in/s3out, or 0x80000000 | y when the symbol bypasses the re-mapper
+__global__ void __launch_bounds__(256) k_map_scatter(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][512];
+    const E1Job &J = jobs[blockIdx.y];
+    const uint8_t *__restrict__ x = J.b.img; const uint16_t *__restrict__ pxs = J.b.pxs;
+    const uint32_t *__restrict__ table = J.b.table; uint16_t *__restrict__ s3in = J.b.s3in; uint32_t *__restrict__ pos3 = J.b.pos3;
+    const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *off = lds[threadIdx.x >> 6];
@@ -232,12 +299,14 @@ __global__ void __launch_bounds__(256) k_map_scatter(const uint8_t *__restrict__
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t t = base + lane_id(), key = 0; int y = 0;
         bool in = t < hi;
-        bool valid = in && mapper_item(x, pxs, t, key, y);
-        if (in && !valid) z[t] = uint8_t(y);                      // y >= 20 codes as itself (NBLIC.c:488)
+        bool valid = in && mapper_item(int(x[t]), pxs[t], key, y);
+        if (in && !valid) pos3[t] = 0x80000000u | uint32_t(y);    // y >= 20 codes as itself (NBLIC.c:488)
         uint64_t same = match_lanes<9>(key, valid);
         if (valid) {
             uint32_t rank = __popcll(same & lanes_below());
-            s3rec[off[key] + rank] = t | (uint32_t(y) << 27);
+            uint32_t pos = off[key] + rank;
+            s3in[pos] = uint16_t(y);
+            pos3[t] = pos;
             if (rank == 0) off[key] += uint32_t(__popcll(same));
         }
     }
@@ -246,70 +315,63 @@ __global__ void __launch_bounds__(256) k_map_scatter(const uint8_t *__restrict__
 // ---- S3: re-mapper chains, one lane per (px, sign) (NBLIC.c:470-523) ----------------------
 // Per-lane state (20 ranks, 20 symbols, 20 counts) lives in LDS as [entry][lane] so that the
 // 64 lanes of a wave hit 64 different banks whatever entry each of them indexes.
-__global__ void __launch_bounds__(64) k_mapper_chains(const uint32_t *__restrict__ s3rec, const uint32_t *__restrict__ table,
-                                                      SegPlan plan, uint32_t n_items_total_dummy, const uint32_t *__restrict__ total,
-                                                      int *__restrict__ map_state, uint8_t *__restrict__ z) {
+__global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ jobs) {
     __shared__ int rank_of[kMapSyms][64], sym_at[kMapSyms][64], count[kMapSyms][64];
-    __shared__ uint32_t stage[64 * kStageRow];
+    __shared__ uint2 stage[64 * kRowWords];
+    const E1Job &J = jobs[blockIdx.y];
+    const uint16_t *__restrict__ s3in = J.b.s3in; const uint32_t *__restrict__ table = J.b.table;
+    const uint32_t *__restrict__ total = J.b.totals + 1; int *__restrict__ map_state = J.b.map_state;
+    uint16_t *__restrict__ s3out = J.b.s3out; const SegPlan plan = J.pp;
     const int lane = int(threadIdx.x);
     const int key = int(blockIdx.x) * 64 + lane;
     int *st = map_state + size_t(key) * (3 * kMapSyms);
     for (int k = 0; k < kMapSyms; k++) {
         rank_of[k][lane] = st[k]; sym_at[k][lane] = st[kMapSyms + k]; count[k][lane] = st[2 * kMapSyms + k];
     }
-    uint32_t r = table[size_t(key) * plan.nseg];
+    const uint32_t start = table[size_t(key) * plan.nseg];
     const uint32_t end = key + 1 < 512 ? table[size_t(key + 1) * plan.nseg] : *total;
-    (void)n_items_total_dummy;
-    for (;;) {
-        uint32_t rem = end - r;
-        uint64_t active = __ballot(rem > 0u);
-        if (active == 0ull) break;
-        stage_streams(s3rec, stage, r, rem, active);
-        __syncthreads();
-        const int mine = int(min(rem, 64u));
-        for (int i = 0; i < 64; i++) {
-            if (__ballot(i < mine) == 0ull) break;
-            if (i < mine) {
-                uint32_t cur = stage[lane * kStageRow + i];
-                int y = int(cur >> 27);
-                int zz = rank_of[y][lane];
-                z[cur & 0x7FFFFFFu] = uint8_t(zz);
-                int c = count[zz][lane] + 1;
-                count[zz][lane] = c;
-                if (zz > 0) {
-                    int c_up = count[zz - 1][lane];
-                    if (c_up < c) {                               // overtake the rank above
-                        int other = sym_at[zz - 1][lane];
-                        count[zz][lane] = c_up;  count[zz - 1][lane] = c;
-                        sym_at[zz][lane] = other; sym_at[zz - 1][lane] = y;
-                        rank_of[y][lane] = zz - 1; rank_of[other][lane] = zz;
-                    }
-                }
+    run_lane_streams(s3in, s3out, start, end, stage, [&](uint32_t y) {
+        int zz = rank_of[y][lane];
+        int c = count[zz][lane] + 1;
+        count[zz][lane] = c;
+        if (zz > 0) {
+            int c_up = count[zz - 1][lane];
+            if (c_up < c) {                                       // overtake the rank above
+                int other = sym_at[zz - 1][lane];
+                count[zz][lane] = c_up;  count[zz - 1][lane] = c;
+                sym_at[zz][lane] = other; sym_at[zz - 1][lane] = int(y);
+                rank_of[y][lane] = zz - 1; rank_of[other][lane] = zz;
             }
         }
-        r += uint32_t(mine);
-        __syncthreads();
-    }
+        return uint32_t(zz);
+    });
     for (int k = 0; k < kMapSyms; k++) {
         st[k] = rank_of[k][lane]; st[kMapSyms + k] = sym_at[k][lane]; st[2 * kMapSyms + k] = count[k][lane];
     }
 }
 
 // ---- S4: binarisation (NBLIC.c:640-679); path depends on (qu,qv,qw,z) only ----------------
-__global__ void __launch_bounds__(256) k_count_bins(const uint32_t *__restrict__ rec1, const uint8_t *__restrict__ z, uint32_t n,
-                                                    uint8_t *__restrict__ cnt) {
+__global__ void __launch_bounds__(256) k_count_bins(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.y];
+    const uint32_t *__restrict__ rec1 = J.b.rec1; const uint16_t *__restrict__ s3out = J.b.s3out;
+    const uint32_t *__restrict__ pos3 = J.b.pos3; uint8_t *__restrict__ z = J.b.z; uint8_t *__restrict__ cnt = J.b.cnt;
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n) return;
+    if (t >= J.n) return;
     Level L = s1_level(rec1[t]);
+    uint32_t p = pos3[t];
+    int zz = (p >> 31) ? int(p & 0xFF) : int(s3out[p]);           // back to raster order
+    z[t] = uint8_t(zz);
     int c = 0;
-    walk_symbol(kMinKStep, L.qu, L.qv, int(z[t]), [&](int, int, int, int bin) { c++; return bin; });
+    walk_symbol(kMinKStep, L.qu, L.qv, zz, [&](int, int, int, int bin) { c++; return bin; });
     cnt[t] = uint8_t(c);
 }
 
-__global__ void __launch_bounds__(256) k_emit_bins(const uint32_t *__restrict__ rec1, const uint8_t *__restrict__ z, uint32_t n,
-                                                   const uint32_t *__restrict__ ev_off, uint32_t *__restrict__ events) {
+__global__ void __launch_bounds__(256) k_emit_bins(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.y];
+    const uint32_t *__restrict__ rec1 = J.b.rec1; const uint8_t *__restrict__ z = J.b.z;
+    const uint32_t *__restrict__ ev_off = J.b.ev_off; uint32_t *__restrict__ events = J.b.events;
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n) return;
+    if (t >= J.n) return;
     Level L = s1_level(rec1[t]);
     uint32_t *out = events + ev_off[t];
     walk_symbol(kMinKStep, L.qu, L.qv, int(z[t]), [&](int qu, int qv, int node, int bin) {
@@ -323,12 +385,13 @@ __global__ void __launch_bounds__(256) k_emit_bins(const uint32_t *__restrict__ 
 // odd: per parity an event contributes AT MOST one touch, which keeps the ranking a plain
 // one-key match.  An event whose two trees coincide touches that one counter twice
 // (weights 32-qw then qw, NBLIC.c:635-636) and is carried as a single "double" item.
-struct Touch { bool valid; uint32_t key; uint32_t payload; };
+// Touch payload (u16):  w1[0:6) | w2[6:12) | bin[12] | double[13]
+struct Touch { bool valid; uint32_t key; uint32_t payload; int slot; };
 
 __device__ __forceinline__ Touch touch_of(uint32_t e, int parity) {
     int qu = ev_qu(e), qv = ev_qv(e), node = ev_node(e), qw = ev_qw(e), bin = ev_bin(e);
-    Touch t{false, 0u, 0u};
-    int tree, w1, w2 = 0, slot = 0, dbl = 0;
+    Touch t{false, 0u, 0u, 0};
+    int tree, w1, w2 = 0, dbl = 0;
     if (qu == qv) {
         if ((qu & 1) != parity) return t;
         tree = qu; w1 = kWeightOne - qw; w2 = qw; dbl = 1;
@@ -336,17 +399,19 @@ __device__ __forceinline__ Touch touch_of(uint32_t e, int parity) {
         tree = qu; w1 = kWeightOne - qw;
     } else {
         if (qw == 0) return t;                   // weight-0 touch: no state change, its P is multiplied by 0
-        tree = qv; w1 = qw; slot = 1;
+        tree = qv; w1 = qw; t.slot = 1;
     }
     t.valid = true;
     t.key = uint32_t(parity) * 2048u + uint32_t(tree >> 1) * 256u + uint32_t(node);
-    t.payload = uint32_t(w1) | (uint32_t(w2) << 6) | (uint32_t(bin) << 12) | (uint32_t(slot) << 13) | (uint32_t(dbl) << 14);
+    t.payload = uint32_t(w1) | (uint32_t(w2) << 6) | (uint32_t(bin) << 12) | (uint32_t(dbl) << 13);
     return t;
 }
 
-__global__ void __launch_bounds__(256) k_touch_count(const uint32_t *__restrict__ events, uint32_t n_ev, SegPlan plan,
-                                                     uint32_t *__restrict__ table) {
+__global__ void __launch_bounds__(256) k_touch_count(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][4096];
+    const E1Job &J = jobs[blockIdx.y];
+    const uint32_t *__restrict__ events = J.b.events; uint32_t *__restrict__ table = J.b.table;
+    const uint32_t n_ev = J.n_ev; const SegPlan plan = J.pe;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *hist = lds[threadIdx.x >> 6];
@@ -364,9 +429,13 @@ __global__ void __launch_bounds__(256) k_touch_count(const uint32_t *__restrict_
     for (int k = lane_id(); k < 4096; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
 }
 
-__global__ void __launch_bounds__(256) k_touch_scatter(const uint32_t *__restrict__ events, uint32_t n_ev, SegPlan plan,
-                                                       const uint32_t *__restrict__ table, uint2 *__restrict__ touch) {
+// tpos[2r] / tpos[2r+1] = where event r's tree-u / tree-v probability will appear in tout[]
+__global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][4096];
+    const E1Job &J = jobs[blockIdx.y];
+    const uint32_t *__restrict__ events = J.b.events; const uint32_t *__restrict__ table = J.b.table;
+    uint16_t *__restrict__ tin = J.b.tin; uint2 *__restrict__ tpos = reinterpret_cast<uint2 *>(J.b.tpos);
+    const uint32_t n_ev = J.n_ev; const SegPlan plan = J.pe;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *off = lds[threadIdx.x >> 6];
@@ -375,126 +444,133 @@ __global__ void __launch_bounds__(256) k_touch_scatter(const uint32_t *__restric
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t r = base + lane_id();
         uint32_t e = r < hi ? events[r] : 0u;
+        uint32_t pos_u = 0, pos_v = 0;
+        bool have_v = false;
 #pragma unroll
         for (int parity = 0; parity < 2; parity++) {
             Touch t = touch_of(e, parity);
             bool valid = r < hi && t.valid;
-            uint64_t same = match_lanes<11>(t.key, valid);       // parity bit is common to the pass
+            uint64_t same = match_lanes<11>(t.key, valid);       // the parity bit is common to the pass
             if (valid) {
                 uint32_t rank = __popcll(same & lanes_below());
-                touch[off[t.key] + rank] = make_uint2(r, t.payload);
+                uint32_t pos = off[t.key] + rank;
+                tin[pos] = uint16_t(t.payload);
+                if (t.slot) { pos_v = pos; have_v = true; } else pos_u = pos;
                 if (rank == 0) off[t.key] += uint32_t(__popcll(same));
             }
         }
+        if (r < hi) tpos[r] = make_uint2(pos_u, have_v ? pos_v : pos_u);
     }
 }
 
 // ---- S5: counter chains, one wave per counter (NBLIC.c:589-637) ---------------------------
 // Between two halvings a counter is a pure running sum, and a halving needs the sum to climb
-// from <= 4129 past 8192 in steps <= 32, i.e. >= 127 touches.  Each iteration takes 256 touches
-// (4 consecutive ones per lane, read as two 16-byte loads, next chunk prefetched), prefix-sums
-// the weights on the DPP crossbar, and then resolves the (at most three) halvings that fall in
-// the chunk one epoch at a time; every other touch is plain arithmetic on its prefix.
-struct TouchQuad { uint32_t ev[4]; uint32_t pay[4]; };
+// from <= 4129 past 8192 in steps <= 32, i.e. >= 127 touches.  Each iteration takes a 512-touch
+// aligned window (one 16-byte load per lane = 8 consecutive touches, next window prefetched),
+// prefix-sums the weights on the DPP crossbar and resolves the halvings that fall in the
+// window one epoch at a time; every other touch is plain arithmetic on its prefix.  Output is
+// P(bin==1) of the touched counter BEFORE the touch, written back as one 16-byte store per lane.
+constexpr int kTpl = 8;                  // touches per lane per window
 
-__device__ __forceinline__ TouchQuad load_quad(const uint2 *__restrict__ touch, uint32_t first, uint32_t end) {
-    TouchQuad q;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint2 t = (first + k < end) ? touch[first + k] : make_uint2(0u, 0u);
-        q.ev[k] = t.x; q.pay[k] = t.y;
-    }
-    return q;
-}
-
-__global__ void __launch_bounds__(64) k_counter_chains(const uint2 *__restrict__ touch, const uint32_t *__restrict__ table,
-                                                       SegPlan plan, const uint32_t *__restrict__ total,
-                                                       int2 *__restrict__ cnt_state, uint16_t *__restrict__ puv) {
+__global__ void __launch_bounds__(64) k_counter_chains(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.y];
+    const uint16_t *__restrict__ tin = J.b.tin; const uint32_t *__restrict__ table = J.b.table;
+    const uint32_t *__restrict__ total = J.b.totals + 3; int2 *__restrict__ cnt_state = reinterpret_cast<int2 *>(J.b.cnt_state);
+    uint16_t *__restrict__ tout = J.b.tout; const SegPlan plan = J.pe;
     const int key = int(blockIdx.x);
     const int lane = int(threadIdx.x);
     const uint32_t start = table[size_t(key) * plan.nseg];
     const uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * plan.nseg] : *total;
     if (start >= end) return;
+    const uint4 *in_w = reinterpret_cast<const uint4 *>(tin);
+    uint4 *out_w = reinterpret_cast<uint4 *>(tout);
     int2 st = cnt_state[key];
     int base_s = st.x + st.y, base_1 = st.y;                         // wave-uniform running state
-    TouchQuad nxt = load_quad(touch, start + uint32_t(lane) * 4u, end);
-    for (uint32_t chunk = start; chunk < end; chunk += 256u) {
-        const TouchQuad q = nxt;
-        const uint32_t first = chunk + uint32_t(lane) * 4u;
-        if (chunk + 256u < end) nxt = load_quad(touch, first + 256u, end);
-        int tot[4], one[4], tex[4], oex[4];
+    const uint32_t first_window = start & ~7u;
+    uint4 nxt = in_w[(first_window >> 3) + lane];
+    for (uint32_t window = first_window; window < end; window += 64u * kTpl) {
+        const uint4 w = nxt;
+        const uint32_t first = window + uint32_t(lane) * kTpl;
+        if (window + 64u * kTpl < end) nxt = in_w[((window + 64u * kTpl) >> 3) + lane];
+        const uint32_t pay[kTpl] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+        int tot[kTpl], one[kTpl], tex[kTpl], oex[kTpl];
         int lt = 0, lo = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int w = int(q.pay[k] & 63) + int((q.pay[k] >> 6) & 63);
-            tot[k] = (first + k < end) ? w : 0;
-            one[k] = ((q.pay[k] >> 12) & 1) ? tot[k] : 0;
+        for (int k = 0; k < kTpl; k++) {
+            const bool ok = first + k >= start && first + k < end;
+            tot[k] = ok ? int(pay[k] & 63) + int((pay[k] >> 6) & 63) : 0;
+            one[k] = ((pay[k] >> 12) & 1) ? tot[k] : 0;
             tex[k] = lt; oex[k] = lo; lt += tot[k]; lo += one[k];
         }
         uint32_t incl = wave_scan_incl_dpp((uint32_t(lt) << 16) | uint32_t(lo));
         const int lane_t = int(incl >> 16) - lt, lane_o = int(incl & 0xFFFF) - lo;    // exclusive over lanes
-        const int chunk_t = int(read_lane(incl, 63) >> 16), chunk_o = int(read_lane(incl, 63) & 0xFFFF);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { tex[k] += lane_t; oex[k] += lane_o; }
+        const uint32_t last = read_lane(incl, 63);
+        const int win_t = int(last >> 16), win_o = int(last & 0xFFFF);
         // virtual base: state before touch j of the current epoch = vb + exclusive prefix(j)
-        int vb_s = base_s, vb_1 = base_1;
-        int from = 0;                                               // first touch (chunk-relative) of the epoch
-        int s_pre[4], c1_pre[4];
+        int vb_s = base_s + lane_t, vb_1 = base_1 + lane_o;         // per lane: lane offset folded in
+        int from = 0;                                               // first touch (window-relative) of the epoch
+        int s_pre[kTpl], c1_pre[kTpl];
         for (;;) {
-            int trig = 4;
+            int trig = kTpl;
 #pragma unroll
-            for (int k = 3; k >= 0; k--) {
-                int j = lane * 4 + k;
-                if (j >= from) {
+            for (int k = kTpl - 1; k >= 0; k--) {
+                if (lane * kTpl + k >= from) {
                     s_pre[k] = vb_s + tex[k]; c1_pre[k] = vb_1 + oex[k];
                     if (s_pre[k] + tot[k] > kCountLimit) trig = k;
                 }
             }
-            uint64_t over = __ballot(trig < 4);
+            uint64_t over = __ballot(trig < kTpl);
             if (over == 0ull) break;
             const int H = __ffsll((unsigned long long)over) - 1;    // first lane with a halving, uniform
             const int hk = int(read_lane(uint32_t(trig), H));
-            int sel_s = s_pre[0], sel_1 = c1_pre[0], sel_tex = tex[0], sel_oex = oex[0], sel_tot = tot[0], sel_one = one[0];
-            uint32_t sel_pay = q.pay[0];
+            int sel_s = s_pre[0], sel_1 = c1_pre[0], sel_tin = tex[0] + tot[0], sel_oin = oex[0] + one[0];
+            uint32_t sel_pay = pay[0];
 #pragma unroll
-            for (int k = 1; k < 4; k++)
-                if (hk == k) { sel_s = s_pre[k]; sel_1 = c1_pre[k]; sel_tex = tex[k]; sel_oex = oex[k]; sel_tot = tot[k]; sel_one = one[k]; sel_pay = q.pay[k]; }
+            for (int k = 1; k < kTpl; k++)
+                if (hk == k) { sel_s = s_pre[k]; sel_1 = c1_pre[k]; sel_tin = tex[k] + tot[k]; sel_oin = oex[k] + one[k]; sel_pay = pay[k]; }
             const int hs = int(read_lane(uint32_t(sel_s), H)), h1 = int(read_lane(uint32_t(sel_1), H));
             const uint32_t hp = read_lane(sel_pay, H);
-            const int h_tin = int(read_lane(uint32_t(sel_tex + sel_tot), H)), h_oin = int(read_lane(uint32_t(sel_oex + sel_one), H));
+            // inclusive prefix of the triggering touch, window-relative (lane offset of lane H included)
+            const int h_tin = int(read_lane(uint32_t(sel_tin + lane_t), H)), h_oin = int(read_lane(uint32_t(sel_oin + lane_o), H));
             Counter c{hs - h1, h1};
             const int hb = int((hp >> 12) & 1), hw1 = int(hp & 63), hw2 = int((hp >> 6) & 63);
             counter_add(c, hb, hw1);
             if (hw2) counter_add(c, hb, hw2);                       // state after the triggering touch
-            vb_s = c.c0 + c.c1 - h_tin; vb_1 = c.c1 - h_oin;
-            from = H * 4 + hk + 1;
+            vb_s = c.c0 + c.c1 - h_tin + lane_t; vb_1 = c.c1 - h_oin + lane_o;
+            from = H * kTpl + hk + 1;
         }
-        base_s = vb_s + chunk_t; base_1 = vb_1 + chunk_o;
+        base_s = int(read_lane(uint32_t(vb_s - lane_t), 0)) + win_t; base_1 = int(read_lane(uint32_t(vb_1 - lane_o), 0)) + win_o;
+        uint32_t p[kTpl];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (first + k < end) {
-                uint16_t p = uint16_t(counter_p1(s_pre[k] - c1_pre[k], c1_pre[k]));
-                size_t o = size_t(q.ev[k]) * 2;
-                if ((q.pay[k] >> 14) & 1) { puv[o] = p; puv[o + 1] = p; } else puv[o + ((q.pay[k] >> 13) & 1)] = p;
-            }
+        for (int k = 0; k < kTpl; k++) p[k] = prob_one(c1_pre[k], s_pre[k]);
+        if (first >= start && first + kTpl <= end) {
+            out_w[first >> 3] = make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTpl; k++) if (first + k >= start && first + k < end) tout[first + k] = uint16_t(p[k]);
         }
     }
     if (lane == 0) cnt_state[key] = make_int2(base_s - base_1, base_1);
 }
 
 // ---- mix the two trees' probabilities and pack for the host coder (NBLIC.c:629-633) -------
-__global__ void __launch_bounds__(256) k_mix(const uint32_t *__restrict__ events, const uint16_t *__restrict__ puv, uint32_t n_ev,
-                                             uint16_t *__restrict__ coded) {
+__global__ void __launch_bounds__(256) k_mix(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.y];
+    const uint32_t *__restrict__ events = J.b.events; const uint16_t *__restrict__ tout = J.b.tout;
+    const uint2 *__restrict__ tpos = reinterpret_cast<const uint2 *>(J.b.tpos); uint16_t *__restrict__ coded = J.b.coded;
     uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= n_ev) return;
+    if (r >= J.n_ev) return;
     uint32_t e = events[r];
+    uint2 tp = tpos[r];
     int qw = ev_qw(e);
-    int pu = puv[size_t(r) * 2], pv = qw ? int(puv[size_t(r) * 2 + 1]) : 0;
+    int pu = tout[tp.x], pv = tout[tp.y];
     coded[r] = pack_coded(mix_prob(pu, pv, qw), ev_bin(e));
 }
 
 // ---- model state init (NBLIC.c:797-804) ---------------------------------------------------
-__global__ void k_init_state(int *ctx_state, int *map_state, int2 *cnt_state) {
+__global__ void k_init_state(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.y];
+    int *ctx_state = J.b.ctx_state, *map_state = J.b.map_state; int2 *cnt_state = reinterpret_cast<int2 *>(J.b.cnt_state);
     int g = int(blockIdx.x) * 256 + int(threadIdx.x);
     if (g < kContexts) ctx_state[g] = 0;
     if (g < 4096) cnt_state[g] = make_int2(kWeightOne, kWeightOne);
@@ -507,22 +583,37 @@ __global__ void k_init_state(int *ctx_state, int *map_state, int2 *cnt_state) {
 // ------------------------------------------------------------------------------------------
 // exclusive scan (u32 out) over u32 or u8 input: reduce -> scan block sums -> apply
 // ------------------------------------------------------------------------------------------
+// WHICH selects the job's array: 0 adr table, 1 mapper table, 2 bin counts (u8), 3 touch table.
 constexpr int kScanThreads = 256, kScanPerThread = 16, kScanTile = kScanThreads * kScanPerThread;
 
-template <class T>
-__global__ void __launch_bounds__(kScanThreads) k_scan_reduce(const T *__restrict__ in, uint32_t n, uint32_t *__restrict__ sums) {
+template <int WHICH> struct ScanSel;
+template <> struct ScanSel<0> { typedef uint32_t T; static __device__ const T *in(const E1Job &J) { return J.b.table; }  static __device__ uint32_t *out(const E1Job &J) { return J.b.table; }  static __device__ uint32_t n(const E1Job &J) { return uint32_t(kContexts) * J.pp.nseg; } };
+template <> struct ScanSel<1> { typedef uint32_t T; static __device__ const T *in(const E1Job &J) { return J.b.table; }  static __device__ uint32_t *out(const E1Job &J) { return J.b.table; }  static __device__ uint32_t n(const E1Job &J) { return 512u * J.pp.nseg; } };
+template <> struct ScanSel<2> { typedef uint8_t  T; static __device__ const T *in(const E1Job &J) { return J.b.cnt; }    static __device__ uint32_t *out(const E1Job &J) { return J.b.ev_off; } static __device__ uint32_t n(const E1Job &J) { return J.n; } };
+template <> struct ScanSel<3> { typedef uint32_t T; static __device__ const T *in(const E1Job &J) { return J.b.table; }  static __device__ uint32_t *out(const E1Job &J) { return J.b.table; }  static __device__ uint32_t n(const E1Job &J) { return 4096u * J.pe.nseg; } };
+
+template <int WHICH>
+__global__ void __launch_bounds__(kScanThreads) k_scan_reduce(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t part[kScanThreads / 64];
+    const E1Job &J = jobs[blockIdx.y];
+    const typename ScanSel<WHICH>::T *in = ScanSel<WHICH>::in(J);
+    const uint32_t n = ScanSel<WHICH>::n(J);
     uint32_t base = blockIdx.x * uint32_t(kScanTile) + threadIdx.x * kScanPerThread, s = 0;
+    if (blockIdx.x * uint32_t(kScanTile) >= n) return;
     for (int k = 0; k < kScanPerThread; k++) if (base + k < n) s += uint32_t(in[base + k]);
     s = wave_scan_incl(s);
     if (lane_id() == 63) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) J.b.scan_sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *sums, uint32_t nblocks, uint32_t *total) {
+template <int WHICH>
+__global__ void __launch_bounds__(1024) k_scan_sums(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t part[16];
     __shared__ uint32_t carry;
+    const E1Job &J = jobs[blockIdx.y];
+    uint32_t *sums = J.b.scan_sums;
+    const uint32_t nblocks = (ScanSel<WHICH>::n(J) + kScanTile - 1) / kScanTile;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < nblocks; base += 1024) {
@@ -538,20 +629,24 @@ __global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *sums, uint32_t nbl
         if (threadIdx.x == 1023) carry = pre + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) J.b.totals[WHICH] = carry;
 }
 
-template <class T>
-__global__ void __launch_bounds__(kScanThreads) k_scan_apply(const T *in, uint32_t n, const uint32_t *__restrict__ sums,
-                                                             uint32_t *out) {   // in may alias out (each thread re-writes its own items)
+template <int WHICH>
+__global__ void __launch_bounds__(kScanThreads) k_scan_apply(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t part[kScanThreads / 64];
+    const E1Job &J = jobs[blockIdx.y];
+    const typename ScanSel<WHICH>::T *in = ScanSel<WHICH>::in(J);     // may alias out (each thread re-writes its own items)
+    uint32_t *out = ScanSel<WHICH>::out(J);
+    const uint32_t n = ScanSel<WHICH>::n(J);
+    if (blockIdx.x * uint32_t(kScanTile) >= n) return;
     uint32_t base = blockIdx.x * uint32_t(kScanTile) + threadIdx.x * kScanPerThread;
     uint32_t v[kScanPerThread], s = 0;
     for (int k = 0; k < kScanPerThread; k++) { v[k] = base + k < n ? uint32_t(in[base + k]) : 0u; s += v[k]; }
     uint32_t incl = wave_scan_incl(s);
     if (lane_id() == 63) part[threadIdx.x >> 6] = incl;
     __syncthreads();
-    uint32_t pre = sums[blockIdx.x] + incl - s;
+    uint32_t pre = J.b.scan_sums[blockIdx.x] + incl - s;
     for (int wv = 0; wv < int(threadIdx.x >> 6); wv++) pre += part[wv];
     for (int k = 0; k < kScanPerThread; k++) { if (base + k < n) out[base + k] = pre; pre += v[k]; }
 }
@@ -586,13 +681,13 @@ struct Marker {                       // records one event in front of every lau
     void operator()() { if (tm) hipEventRecord(tm->ev[k], s); k++; }
 };
 
-template <class T>
-static void scan_exclusive(const T *in, uint32_t n, uint32_t *out, uint32_t *sums, uint32_t *total, hipStream_t s, Marker &mark) {
-    unsigned nb = cdiv(n, kScanTile);
-    if (nb == 0) { mark(); mark(); mark(); hipMemsetAsync(total, 0, 4, s); return; }
-    mark(); hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb), dim3(kScanThreads), 0, s, in, n, sums);
-    mark(); hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, nb, total);
-    mark(); hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(kScanThreads), 0, s, in, n, sums, out);
+template <int WHICH>
+static void scan_exclusive(const E1Job *jobs, int n_jobs, uint32_t max_items, hipStream_t s, Marker &mark) {
+    unsigned nb = cdiv(max_items, kScanTile);
+    if (nb == 0) nb = 1;
+    mark(); hipLaunchKernelGGL(k_scan_reduce<WHICH>, dim3(nb, n_jobs), dim3(kScanThreads), 0, s, jobs);
+    mark(); hipLaunchKernelGGL(k_scan_sums<WHICH>, dim3(1, n_jobs), dim3(1024), 0, s, jobs);
+    mark(); hipLaunchKernelGGL(k_scan_apply<WHICH>, dim3(nb, n_jobs), dim3(kScanThreads), 0, s, jobs);
 }
 
 SegPlan make_plan(uint32_t n_items) {
@@ -605,43 +700,47 @@ SegPlan make_plan(uint32_t n_items) {
     return p;
 }
 
-void e1_init_state(const E1Buffers &b, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_state, dim3(16), dim3(256), 0, s, b.ctx_state, b.map_state, (int2 *)b.cnt_state);
-}
-
-// Stage group A: everything up to the per-pixel bin counts and their scan (the event total
-// is needed on the host before the event buffers can be sized).  17 launches.
-void e1_launch_front(const E1Buffers &b, int h, int w, hipStream_t s, E1Timers *tm) {
-    const uint32_t n = uint32_t(size_t(h) * size_t(w));
-    SegPlan pp = make_plan(n);
+// Front half for a group of jobs: everything up to the per-pixel bin counts and their scan
+// (the event totals are needed on the host before the event buffers can be sized).  18 launches.
+void e1_launch_front(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm) {
+    int max_w = 0, max_h = 0, max_nseg = 0; uint32_t max_n = 0;
+    for (int k = 0; k < n_jobs; k++) {
+        max_w = h_jobs[k].w > max_w ? h_jobs[k].w : max_w; max_h = h_jobs[k].h > max_h ? h_jobs[k].h : max_h;
+        max_n = h_jobs[k].n > max_n ? h_jobs[k].n : max_n; max_nseg = h_jobs[k].pp.nseg > max_nseg ? h_jobs[k].pp.nseg : max_nseg;
+    }
+    const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs), px_grid(cdiv(max_n, 256), n_jobs);
     Marker mark{tm, s, 0};
-    mark(); hipLaunchKernelGGL(k_predict, dim3(cdiv(w, 256), h), dim3(256), 0, s, b.img, h, w, 0, h, b.rec1);
-    mark(); hipLaunchKernelGGL(k_adr_count, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.rec1, n, pp, b.table);
-    scan_exclusive<uint32_t>(b.table, uint32_t(kContexts) * pp.nseg, b.table, b.scan_sums, b.totals + 0, s, mark);
-    mark(); hipLaunchKernelGGL(k_adr_scatter, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.rec1, b.img, n, pp, b.table, (uint2 *)b.s2rec);
-    mark(); hipLaunchKernelGGL(k_bias_chains, dim3(kContexts / 64), dim3(64), 0, s, (const uint2 *)b.s2rec, b.table, pp, n, b.ctx_state, b.pxs);
-    mark(); hipLaunchKernelGGL(k_map_count, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.img, b.pxs, n, pp, b.table);
-    scan_exclusive<uint32_t>(b.table, 512u * pp.nseg, b.table, b.scan_sums, b.totals + 1, s, mark);
-    mark(); hipLaunchKernelGGL(k_map_scatter, dim3(cdiv(pp.nseg, 4)), dim3(256), 0, s, b.img, b.pxs, n, pp, b.table, b.s3rec, b.z);
-    mark(); hipLaunchKernelGGL(k_mapper_chains, dim3(512 / 64), dim3(64), 0, s, b.s3rec, b.table, pp, 0u, b.totals + 1, b.map_state, b.z);
-    mark(); hipLaunchKernelGGL(k_count_bins, dim3(cdiv(n, 256)), dim3(256), 0, s, b.rec1, b.z, n, b.cnt);
-    scan_exclusive<uint8_t>(b.cnt, n, b.ev_off, b.scan_sums, b.totals + 2, s, mark);
-    mark();                                                     // start of the host gap (index 17)
+    mark(); hipLaunchKernelGGL(k_init_state, dim3(16, n_jobs), dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_predict, dim3(cdiv(max_w, 256), max_h, n_jobs), dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_adr_count, seg_grid, dim3(256), 0, s, d_jobs);
+    scan_exclusive<0>(d_jobs, n_jobs, uint32_t(kContexts) * max_nseg, s, mark);
+    mark(); hipLaunchKernelGGL(k_adr_scatter, seg_grid, dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_bias_chains, dim3(kContexts / 64, n_jobs), dim3(64), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_map_count, seg_grid, dim3(256), 0, s, d_jobs);
+    scan_exclusive<1>(d_jobs, n_jobs, 512u * max_nseg, s, mark);
+    mark(); hipLaunchKernelGGL(k_map_scatter, seg_grid, dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_mapper_chains, dim3(512 / 64, n_jobs), dim3(64), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_count_bins, px_grid, dim3(256), 0, s, d_jobs);
+    scan_exclusive<2>(d_jobs, n_jobs, max_n, s, mark);
+    mark();                                                     // start of the host gap (index 18)
 }
 
-// Stage group B: needs n_ev (read back from totals[2]) and event-sized buffers.  8 launches.
-void e1_launch_back(const E1Buffers &b, int h, int w, uint32_t n_ev, hipStream_t s, E1Timers *tm) {
-    const uint32_t n = uint32_t(size_t(h) * size_t(w));
-    SegPlan pe = make_plan(n_ev);
-    Marker mark{tm, s, 18};
-    mark(); hipLaunchKernelGGL(k_emit_bins, dim3(cdiv(n, 256)), dim3(256), 0, s, b.rec1, b.z, n, b.ev_off, b.events);
-    mark(); hipLaunchKernelGGL(k_touch_count, dim3(cdiv(pe.nseg, 4)), dim3(256), 0, s, b.events, n_ev, pe, b.table);
-    scan_exclusive<uint32_t>(b.table, 4096u * pe.nseg, b.table, b.scan_sums, b.totals + 3, s, mark);
-    mark(); hipLaunchKernelGGL(k_touch_scatter, dim3(cdiv(pe.nseg, 4)), dim3(256), 0, s, b.events, n_ev, pe, b.table, (uint2 *)b.touch);
-    mark(); hipLaunchKernelGGL(k_counter_chains, dim3(4096), dim3(64), 0, s, (const uint2 *)b.touch, b.table, pe, b.totals + 3,
-                               (int2 *)b.cnt_state, b.puv);
-    mark(); hipLaunchKernelGGL(k_mix, dim3(cdiv(n_ev, 256)), dim3(256), 0, s, b.events, b.puv, n_ev, b.coded);
-    mark();                                                     // index 26: end
+// Back half: needs n_ev / pe filled in the job records and event-sized buffers.  8 launches.
+void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm) {
+    int max_nseg = 0; uint32_t max_n = 0, max_ev = 0;
+    for (int k = 0; k < n_jobs; k++) {
+        max_n = h_jobs[k].n > max_n ? h_jobs[k].n : max_n; max_ev = h_jobs[k].n_ev > max_ev ? h_jobs[k].n_ev : max_ev;
+        max_nseg = h_jobs[k].pe.nseg > max_nseg ? h_jobs[k].pe.nseg : max_nseg;
+    }
+    const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs);
+    Marker mark{tm, s, 19};
+    mark(); hipLaunchKernelGGL(k_emit_bins, dim3(cdiv(max_n, 256), n_jobs), dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_touch_count, seg_grid, dim3(256), 0, s, d_jobs);
+    scan_exclusive<3>(d_jobs, n_jobs, 4096u * max_nseg, s, mark);
+    mark(); hipLaunchKernelGGL(k_touch_scatter, seg_grid, dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_counter_chains, dim3(4096, n_jobs), dim3(64), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_mix, dim3(cdiv(max_ev, 256) ? cdiv(max_ev, 256) : 1, n_jobs), dim3(256), 0, s, d_jobs);
+    mark();                                                     // index 27: end
 }
 
 }  // namespace nblic

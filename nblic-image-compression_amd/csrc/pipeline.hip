@@ -109,18 +109,25 @@ class Pool {
 
 // ---- one image in flight -------------------------------------------------------------------
 struct Slot {
+    E1Buffers b{};
+    size_t px_cap = 0, ev_cap = 0, img_cap = 0;
+    uint8_t *d_img = nullptr;         // device copy when the caller hands a host image
+    uint16_t *h_coded = nullptr;      // pinned, ev_cap entries: the coded bins for the host coder
+    int job = -1, h = 0, w = 0;       // current image
+    uint32_t n_ev = 0;
+};
+
+// ---- a group of images that shares every kernel launch ---------------------------------------
+struct Group {
     int id = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     E1Timers tm{};
-    E1Buffers b{};
-    size_t px_cap = 0, ev_cap = 0, img_cap = 0, h_cap = 0;
-    uint8_t *d_img = nullptr;         // device copy when the caller hands a host image
-    uint32_t *h_totals = nullptr;     // pinned, 4 words
-    uint16_t *h_coded = nullptr;      // pinned, h_cap entries
-    // current job
-    int job = -1, h = 0, w = 0;
-    uint32_t n_ev = 0;
+    std::vector<Slot> slots;
+    E1Job *h_jobs = nullptr, *d_jobs = nullptr;        // pinned host / device job records
+    uint32_t *h_totals = nullptr, *d_totals = nullptr; // 4 words per slot
+    int n_jobs = 0;
+    int pending = 0;                                   // coder tasks outstanding (guarded by ctx->fm)
 };
 
 template <class T> static bool dev_alloc(T *&p, size_t count) {
@@ -138,13 +145,12 @@ struct nblic_amd_ctx {
     int device = 0;
     long max_px = kMaxPixels;
     bool timing = false;
-    std::vector<Slot> slots;
+    std::vector<Group> groups;
     Pool *pool = nullptr;
     std::mutex api;                       // one batch at a time per context
-    // free-slot list, fed by coder threads
-    std::mutex fm;
+    std::mutex fm;                        // free-group list, fed by coder threads
     std::condition_variable fcv;
-    std::deque<int> free_slots;
+    std::deque<int> free_groups;
     int coding = 0;                       // S6 tasks outstanding
     // reporting
     double stage_ms[kE1Kernels] = {0};
@@ -155,95 +161,121 @@ struct nblic_amd_ctx {
 
 namespace nblic {
 
-static bool slot_init(Slot &s, int id) {
-    s.id = id;
-    HIP_OK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    for (auto &e : s.tm.ev) HIP_OK(hipEventCreate(&e));
-    HIP_OK(hipHostMalloc((void **)&s.h_totals, 4 * sizeof(uint32_t), hipHostMallocDefault));
-    HIP_OK(hipMalloc((void **)&s.b.table, size_t(4096) * kMaxSegments * sizeof(uint32_t)));
-    HIP_OK(hipMalloc((void **)&s.b.scan_sums, size_t(1) << 20));
-    HIP_OK(hipMalloc((void **)&s.b.totals, 4 * sizeof(uint32_t)));
-    HIP_OK(hipMalloc((void **)&s.b.ctx_state, kContexts * sizeof(int)));
-    HIP_OK(hipMalloc((void **)&s.b.map_state, 512 * 60 * sizeof(int)));
-    HIP_OK(hipMalloc((void **)&s.b.cnt_state, 4096 * 2 * sizeof(int)));
+static bool group_init(Group &g, int id, int n_slots) {
+    g.id = id;
+    g.slots.resize(size_t(n_slots));
+    HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    for (auto &e : g.tm.ev) HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipHostMalloc((void **)&g.h_jobs, size_t(n_slots) * sizeof(E1Job), hipHostMallocDefault));
+    HIP_OK(hipMalloc((void **)&g.d_jobs, size_t(n_slots) * sizeof(E1Job)));
+    HIP_OK(hipHostMalloc((void **)&g.h_totals, size_t(n_slots) * 4 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_OK(hipMalloc((void **)&g.d_totals, size_t(n_slots) * 4 * sizeof(uint32_t)));
+    for (int k = 0; k < n_slots; k++) {
+        Slot &s = g.slots[size_t(k)];
+        HIP_OK(hipMalloc((void **)&s.b.table, size_t(4096) * kMaxSegments * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **)&s.b.scan_sums, size_t(1) << 20));
+        s.b.totals = g.d_totals + size_t(k) * 4;
+        HIP_OK(hipMalloc((void **)&s.b.ctx_state, kContexts * sizeof(int)));
+        HIP_OK(hipMalloc((void **)&s.b.map_state, 512 * 60 * sizeof(int)));
+        HIP_OK(hipMalloc((void **)&s.b.cnt_state, 4096 * 2 * sizeof(int)));
+    }
     return true;
 }
 
-static void slot_free(Slot &s) {
-    hipFree(s.b.rec1); hipFree(s.b.s2rec); hipFree(s.b.pxs); hipFree(s.b.s3rec); hipFree(s.b.z); hipFree(s.b.cnt);
-    hipFree(s.b.ev_off); hipFree(s.b.table); hipFree(s.b.scan_sums); hipFree(s.b.totals); hipFree(s.b.ctx_state);
-    hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events); hipFree(s.b.touch); hipFree(s.b.puv);
-    hipFree(s.b.coded); hipFree(s.d_img);
-    if (s.h_totals) hipHostFree(s.h_totals);
-    if (s.h_coded) hipHostFree(s.h_coded);
-    for (auto &e : s.tm.ev) if (e) hipEventDestroy(e);
-    if (s.done) hipEventDestroy(s.done);
-    if (s.stream) hipStreamDestroy(s.stream);
+static void group_free(Group &g) {
+    for (auto &s : g.slots) {
+        hipFree(s.b.rec1); hipFree(s.b.s2in); hipFree(s.b.pos2); hipFree(s.b.s2out); hipFree(s.b.pxs); hipFree(s.b.s3in);
+        hipFree(s.b.pos3); hipFree(s.b.s3out); hipFree(s.b.z); hipFree(s.b.cnt); hipFree(s.b.ev_off); hipFree(s.b.table);
+        hipFree(s.b.scan_sums); hipFree(s.b.ctx_state); hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events);
+        hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.coded); hipFree(s.d_img);
+        if (s.h_coded) hipHostFree(s.h_coded);
+    }
+    hipFree(g.d_jobs); hipFree(g.d_totals);
+    if (g.h_jobs) hipHostFree(g.h_jobs);
+    if (g.h_totals) hipHostFree(g.h_totals);
+    for (auto &e : g.tm.ev) if (e) hipEventDestroy(e);
+    if (g.done) hipEventDestroy(g.done);
+    if (g.stream) hipStreamDestroy(g.stream);
 }
 
 static bool ensure_events(Slot &s, size_t n_ev) {
     if (n_ev <= s.ev_cap) return true;
     size_t cap = n_ev + n_ev / 8 + 1024;
-    if (!dev_alloc(s.b.events, cap) || !dev_alloc(s.b.touch, 2 * cap) || !dev_alloc(s.b.puv, 2 * cap) ||
-        !dev_alloc(s.b.coded, cap)) return false;
+    if (!dev_alloc(s.b.events, cap) || !dev_alloc(s.b.tin, 2 * cap + kStreamPad) || !dev_alloc(s.b.tpos, cap) ||
+        !dev_alloc(s.b.tout, 2 * cap + kStreamPad) || !dev_alloc(s.b.coded, cap)) return false;
     if (s.h_coded) hipHostFree(s.h_coded);
     s.h_coded = nullptr;
     HIP_OK(hipHostMalloc((void **)&s.h_coded, cap * sizeof(uint16_t), hipHostMallocDefault));
-    s.ev_cap = s.h_cap = cap;
+    s.ev_cap = cap;
     return true;
 }
 
 static bool ensure_pixels(Slot &s, size_t n) {
     if (n > s.px_cap) {
         size_t cap = n;
-        if (!dev_alloc(s.b.rec1, cap) || !dev_alloc(s.b.s2rec, cap) || !dev_alloc(s.b.pxs, cap) ||
-            !dev_alloc(s.b.s3rec, cap) || !dev_alloc(s.b.z, cap) || !dev_alloc(s.b.cnt, cap) ||
-            !dev_alloc(s.b.ev_off, cap)) return false;
+        if (!dev_alloc(s.b.rec1, cap) || !dev_alloc(s.b.s2in, cap + kStreamPad) || !dev_alloc(s.b.pos2, cap) ||
+            !dev_alloc(s.b.s2out, cap + kStreamPad) || !dev_alloc(s.b.pxs, cap) || !dev_alloc(s.b.s3in, cap + kStreamPad) ||
+            !dev_alloc(s.b.pos3, cap) || !dev_alloc(s.b.s3out, cap + kStreamPad) || !dev_alloc(s.b.z, cap) ||
+            !dev_alloc(s.b.cnt, cap) || !dev_alloc(s.b.ev_off, cap)) return false;
         s.px_cap = cap;
     }
     return ensure_events(s, 6 * n);          // typical images need 4.3-4.5 bins/px; grown on demand
 }
 
-static bool launch_front(nblic_amd_ctx *c, Slot &s, const uint8_t *img, bool on_device, int h, int w) {
-    size_t n = size_t(h) * size_t(w);
-    if (!ensure_pixels(s, n)) return false;
-    if (on_device) {
-        s.b.img = img;
-    } else {
-        if (n > s.img_cap) { if (!dev_alloc(s.d_img, n)) return false; s.img_cap = n; }
-        HIP_OK(hipMemcpyAsync(s.d_img, img, n, hipMemcpyHostToDevice, s.stream));
-        s.b.img = s.d_img;
+// Front half for the images assigned to group g (slots 0..n_jobs-1 already carry job/h/w).
+static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, bool on_device) {
+    for (int k = 0; k < g.n_jobs; k++) {
+        Slot &s = g.slots[size_t(k)];
+        size_t n = size_t(s.h) * size_t(s.w);
+        if (!ensure_pixels(s, n)) return false;
+        if (on_device) {
+            s.b.img = imgs[s.job];
+        } else {
+            if (n > s.img_cap) { if (!dev_alloc(s.d_img, n)) return false; s.img_cap = n; }
+            HIP_OK(hipMemcpyAsync(s.d_img, imgs[s.job], n, hipMemcpyHostToDevice, g.stream));
+            s.b.img = s.d_img;
+        }
+        E1Job &J = g.h_jobs[k];
+        J.b = s.b; J.h = s.h; J.w = s.w; J.n = uint32_t(n); J.pp = make_plan(J.n); J.n_ev = 0; J.pe = make_plan(0);
     }
-    s.h = h; s.w = w;
-    e1_init_state(s.b, s.stream);
-    e1_launch_front(s.b, h, w, s.stream, c->timing ? &s.tm : nullptr);
-    HIP_OK(hipMemcpyAsync(s.h_totals, s.b.totals, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
+    e1_launch_front(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);
+    HIP_OK(hipMemcpyAsync(g.h_totals, g.d_totals, size_t(g.n_jobs) * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
     return true;
 }
 
-static bool launch_back(nblic_amd_ctx *c, Slot &s) {
-    HIP_OK(hipStreamSynchronize(s.stream));
-    s.n_ev = s.h_totals[2];
-    if (s.n_ev >= 0x7FFFFFFFu) { fprintf(stderr, "[nblic_amd] event count overflow\n"); return false; }
-    if (!ensure_events(s, s.n_ev)) return false;
-    e1_launch_back(s.b, s.h, s.w, s.n_ev, s.stream, c->timing ? &s.tm : nullptr);
-    HIP_OK(hipMemcpyAsync(s.h_coded, s.b.coded, size_t(s.n_ev) * sizeof(uint16_t), hipMemcpyDeviceToHost, s.stream));
-    HIP_OK(hipEventRecord(s.done, s.stream));
+static bool launch_back(nblic_amd_ctx *c, Group &g) {
+    HIP_OK(hipStreamSynchronize(g.stream));
+    for (int k = 0; k < g.n_jobs; k++) {
+        Slot &s = g.slots[size_t(k)];
+        s.n_ev = g.h_totals[size_t(k) * 4 + 2];
+        if (s.n_ev >= 0x7FFFFFFFu) { fprintf(stderr, "[nblic_amd] event count overflow\n"); return false; }
+        if (!ensure_events(s, s.n_ev)) return false;
+        E1Job &J = g.h_jobs[k];
+        J.b = s.b; J.n_ev = s.n_ev; J.pe = make_plan(s.n_ev);
+    }
+    HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
+    e1_launch_back(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);
+    for (int k = 0; k < g.n_jobs; k++) {
+        Slot &s = g.slots[size_t(k)];
+        HIP_OK(hipMemcpyAsync(s.h_coded, s.b.coded, size_t(s.n_ev) * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
+    }
+    HIP_OK(hipEventRecord(g.done, g.stream));
     return true;
 }
 
-static void collect_timing(nblic_amd_ctx *c, Slot &s) {
+static void collect_timing(nblic_amd_ctx *c, Group &g) {
     if (!c->timing) return;
     for (int k = 0; k < kE1Kernels; k++) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.tm.ev[k], s.tm.ev[k + 1]) == hipSuccess) c->stage_ms[k] += ms;
+        if (hipEventElapsedTime(&ms, g.tm.ev[k], g.tm.ev[k + 1]) == hipSuccess) c->stage_ms[k] += ms;
     }
     c->stage_launches++;
 }
 
-static void release_slot(nblic_amd_ctx *c, int id, bool was_coding) {
-    { std::lock_guard<std::mutex> g(c->fm); c->free_slots.push_back(id); if (was_coding) c->coding--; }
+static void release_group(nblic_amd_ctx *c, int id) {
+    { std::lock_guard<std::mutex> g(c->fm); c->free_groups.push_back(id); }
     c->fcv.notify_all();
 }
 
@@ -257,64 +289,78 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
     std::deque<int> p1, p2;
     int next = 0;
     bool ok = true;
-    auto submit_coder = [&](Slot &s) {
-        collect_timing(c, s);
-        int job = s.job;
-        { std::lock_guard<std::mutex> g(c->fm); c->coding++; }
-        c->pool->submit([c, &s, job, outs, caps, lens, &stat_m] {
-            auto t0 = std::chrono::steady_clock::now();
-            long len = -1;
-            if (caps[job] >= size_t(kHeaderBytes) + 4) {
-                write_header(outs[job], s.h, s.w, 0, kMinKStep, 1);
-                size_t body = range_code(s.h_coded, s.n_ev, outs[job] + kHeaderBytes, caps[job] - kHeaderBytes);
-                if (body != SIZE_MAX) len = long(kHeaderBytes + body);
-                else fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", job, caps[job]);
-            }
-            lens[job] = len;
-            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            { std::lock_guard<std::mutex> g(stat_m); c->total_bins += double(s.n_ev); c->coder_s += dt; }
-            release_slot(c, s.id, true);
-        });
+    for (int k = 0; k < n_images; k++) lens[k] = -1;
+
+    // hand every image of a finished group to the coder threads; the last one frees the group
+    auto submit_coders = [&](Group &g) {
+        collect_timing(c, g);
+        { std::lock_guard<std::mutex> l(c->fm); g.pending = g.n_jobs; c->coding += g.n_jobs; }
+        for (int k = 0; k < g.n_jobs; k++) {
+            Slot *sp = &g.slots[size_t(k)];
+            Group *gp = &g;
+            c->pool->submit([c, sp, gp, outs, caps, lens, &stat_m] {
+                Slot &s = *sp;
+                auto t0 = std::chrono::steady_clock::now();
+                const int job = s.job;
+                long len = -1;
+                if (caps[job] >= size_t(kHeaderBytes) + 4) {
+                    write_header(outs[job], s.h, s.w, 0, kMinKStep, 1);
+                    size_t body = range_code(s.h_coded, s.n_ev, outs[job] + kHeaderBytes, caps[job] - kHeaderBytes);
+                    if (body != SIZE_MAX) len = long(kHeaderBytes + body);
+                    else fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", job, caps[job]);
+                }
+                lens[job] = len;
+                double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                { std::lock_guard<std::mutex> l(stat_m); c->total_bins += double(s.n_ev); c->coder_s += dt; }
+                bool last;
+                { std::lock_guard<std::mutex> l(c->fm); last = --gp->pending == 0; c->coding--; if (last) c->free_groups.push_back(gp->id); }
+                c->fcv.notify_all();
+            });
+        }
     };
     auto try_acquire = [&](int &id) {
-        std::lock_guard<std::mutex> g(c->fm);
-        if (c->free_slots.empty()) return false;
-        id = c->free_slots.front(); c->free_slots.pop_front();
+        std::lock_guard<std::mutex> l(c->fm);
+        if (c->free_groups.empty()) return false;
+        id = c->free_groups.front(); c->free_groups.pop_front();
         return true;
     };
     for (;;) {
         int id;
         while (next < n_images && try_acquire(id)) {
-            Slot &s = c->slots[id];
-            int k = next++;
-            s.job = k; lens[k] = -1;
-            if (!size_ok(hs[k], ws[k], c->max_px) || !launch_front(c, s, imgs[k], on_device, hs[k], ws[k])) {
-                ok = false; release_slot(c, id, false); continue;
+            Group &g = c->groups[size_t(id)];
+            g.n_jobs = 0;
+            while (next < n_images && g.n_jobs < int(g.slots.size())) {
+                int k = next++;
+                if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; continue; }
+                Slot &s = g.slots[size_t(g.n_jobs++)];
+                s.job = k; s.h = hs[k]; s.w = ws[k];
             }
+            if (g.n_jobs == 0) { release_group(c, id); continue; }
+            if (!launch_front(c, g, imgs, on_device)) { ok = false; hipStreamSynchronize(g.stream); release_group(c, id); continue; }
             p1.push_back(id);
         }
-        while (!p2.empty() && hipEventQuery(c->slots[p2.front()].done) == hipSuccess) {
-            submit_coder(c->slots[p2.front()]); p2.pop_front();
+        while (!p2.empty() && hipEventQuery(c->groups[size_t(p2.front())].done) == hipSuccess) {
+            submit_coders(c->groups[size_t(p2.front())]); p2.pop_front();
         }
         if (!p1.empty()) {
-            Slot &s = c->slots[p1.front()]; p1.pop_front();
-            if (launch_back(c, s)) p2.push_back(s.id);
-            else { ok = false; hipStreamSynchronize(s.stream); release_slot(c, s.id, false); }
+            Group &g = c->groups[size_t(p1.front())]; p1.pop_front();
+            if (launch_back(c, g)) p2.push_back(g.id);
+            else { ok = false; hipStreamSynchronize(g.stream); release_group(c, g.id); }
             continue;
         }
         if (!p2.empty()) {
-            Slot &s = c->slots[p2.front()]; p2.pop_front();
-            if (hipEventSynchronize(s.done) != hipSuccess) { ok = false; release_slot(c, s.id, false); continue; }
-            submit_coder(s);
+            Group &g = c->groups[size_t(p2.front())]; p2.pop_front();
+            if (hipEventSynchronize(g.done) != hipSuccess) { ok = false; release_group(c, g.id); continue; }
+            submit_coders(g);
             continue;
         }
         if (next >= n_images) break;
-        std::unique_lock<std::mutex> g(c->fm);
-        c->fcv.wait(g, [c] { return !c->free_slots.empty(); });
+        std::unique_lock<std::mutex> l(c->fm);
+        c->fcv.wait(l, [c] { return !c->free_groups.empty(); });
     }
     {   // wait for the coder threads
-        std::unique_lock<std::mutex> g(c->fm);
-        c->fcv.wait(g, [c] { return c->coding == 0; });
+        std::unique_lock<std::mutex> l(c->fm);
+        c->fcv.wait(l, [c] { return c->coding == 0; });
     }
     for (int k = 0; k < n_images; k++) if (lens[k] < 0) ok = false;
     return ok;
@@ -346,7 +392,7 @@ size_t nblic_amd_range_code(const uint16_t *coded, size_t n, unsigned char *out,
 
 int nblic_amd_selftest(nblic_amd_ctx *c) {
     if (!c || hipSetDevice(c->device) != hipSuccess) return -1;
-    return e1_selftest(c->slots[0].stream);
+    return e1_selftest(c->groups[0].stream);
 }
 
 void nblic_amd_syn1(unsigned char *img, int h, int w, uint32_t seed) {
@@ -363,7 +409,7 @@ void nblic_amd_syn1(unsigned char *img, int h, int w, uint32_t seed) {
 
 const char *nblic_amd_version(void) { return "nblic_amd 0.1 (NBLIC v0.3 bitstream, gfx950)"; }
 
-nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders) {
+nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int n_coders) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         fprintf(stderr, "[nblic_amd] no HIP device available -- this library has no CPU fallback\n");
@@ -373,25 +419,34 @@ nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders) {
         fprintf(stderr, "[nblic_amd] cannot select HIP device %d of %d\n", device, count);
         return nullptr;
     }
-    if (n_slots < 1) n_slots = 1;
+    if (n_groups < 1) n_groups = 1;
+    if (group_size < 1) group_size = 1;
     if (n_coders < 1) n_coders = 1;
     auto *c = new nblic_amd_ctx;
     c->device = device;
-    c->slots.resize(size_t(n_slots));
-    for (int i = 0; i < n_slots; i++) {
-        if (!slot_init(c->slots[size_t(i)], i)) { nblic_amd_destroy(c); return nullptr; }
-        c->free_slots.push_back(i);
+    c->groups.resize(size_t(n_groups));
+    for (int i = 0; i < n_groups; i++) {
+        if (!group_init(c->groups[size_t(i)], i, group_size)) { nblic_amd_destroy(c); return nullptr; }
+        c->free_groups.push_back(i);
     }
     if (!c->serial.init()) { nblic_amd_destroy(c); return nullptr; }
     c->pool = new Pool(n_coders);
     return c;
 }
 
+nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders) {
+    // images in flight are split into groups that share kernel launches: two groups, so the GPU
+    // works on one while the host codes the other
+    if (n_slots < 1) n_slots = 1;
+    int n_groups = n_slots >= 2 ? 2 : 1;
+    return nblic_amd_create_ex(device, n_groups, (n_slots + n_groups - 1) / n_groups, n_coders);
+}
+
 void nblic_amd_destroy(nblic_amd_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     delete c->pool;
-    for (auto &s : c->slots) slot_free(s);
+    for (auto &g : c->groups) group_free(g);
     c->serial.destroy();
     delete c;
 }
@@ -404,6 +459,8 @@ int nblic_amd_stage_times(nblic_amd_ctx *c, double *ms, const char **names, int 
     for (int k = 0; k < n && k < cap; k++) { ms[k] = c->stage_ms[k]; if (names) names[k] = kE1StageNames[k]; }
     return n < cap ? n : cap;
 }
+
+long nblic_amd_last_launches(nblic_amd_ctx *c) { return c->stage_launches; }
 
 void nblic_amd_last_stats(nblic_amd_ctx *c, double *total_bins, double *coder_seconds_sum) {
     if (total_bins) *total_bins = c->total_bins;
@@ -423,11 +480,14 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
     std::lock_guard<std::mutex> g(c->api);
     if (hipSetDevice(c->device) != hipSuccess) return -1;
     int id;
-    { std::unique_lock<std::mutex> l(c->fm); c->fcv.wait(l, [c] { return !c->free_slots.empty(); }); id = c->free_slots.front(); c->free_slots.pop_front(); }
-    Slot &s = c->slots[size_t(id)];
+    { std::unique_lock<std::mutex> l(c->fm); c->fcv.wait(l, [c] { return !c->free_groups.empty(); }); id = c->free_groups.front(); c->free_groups.pop_front(); }
+    Group &grp = c->groups[size_t(id)];
+    Slot &s = grp.slots[0];
+    grp.n_jobs = 1; s.job = 0; s.h = h; s.w = w;
+    const uint8_t *imgs[1] = {img};
     long count = -1;
     size_t n = size_t(h) * size_t(w);
-    if (launch_front(c, s, img, false, h, w) && launch_back(c, s) && hipStreamSynchronize(s.stream) == hipSuccess) {
+    if (launch_front(c, grp, imgs, false) && launch_back(c, grp) && hipStreamSynchronize(grp.stream) == hipSuccess) {
         const void *src = nullptr; size_t esz = 0, cnt = 0;
         switch (which) {
             case 0: src = s.b.rec1; esz = 4; cnt = n; break;
@@ -440,7 +500,7 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
         }
         if (src && cnt * esz <= out_bytes && hipMemcpy(out, src, cnt * esz, hipMemcpyDeviceToHost) == hipSuccess) count = long(cnt);
     }
-    release_slot(c, id, false);
+    release_group(c, id);
     return count;
 }
 
