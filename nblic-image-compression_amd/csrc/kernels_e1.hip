@@ -32,6 +32,20 @@ namespace nblic {
 // ------------------------------------------------------------------------------------------
 // wave helpers
 // ------------------------------------------------------------------------------------------
+// Pointers that are read out of the job record are generic ("flat") to the compiler; telling it
+// they are global memory turns flat_load/flat_store into global_load/global_store and keeps the
+// LDS counter out of every memory wait.
+#define NB_GLOBAL __attribute__((address_space(1)))
+// plain clang vectors: unlike HIP's uint2/uint4 classes they can be loaded/stored through
+// address-space-qualified pointers
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ NB_GLOBAL T *gptr(T *p) {
+    return (NB_GLOBAL T *)p;
+}
+
 __device__ __forceinline__ int lane_id() { return int(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
 
@@ -93,11 +107,11 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) { return uint32
 constexpr int kRowWords = 65;
 
 template <class StepFn>
-__device__ __forceinline__ void run_lane_streams(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, uint32_t r,
-                                                 const uint32_t end, uint2 *stage, StepFn step) {
+__device__ __forceinline__ void run_lane_streams(NB_GLOBAL const uint16_t *in, NB_GLOBAL uint16_t *out, uint32_t r,
+                                                 const uint32_t end, u32x2 *stage, StepFn step) {
     const int lane = lane_id();
-    const uint2 *in_w = reinterpret_cast<const uint2 *>(in);
-    uint2 *out_w = reinterpret_cast<uint2 *>(out);
+    const auto in_w = (NB_GLOBAL const u32x2 *)in;
+    const auto out_w = (NB_GLOBAL u32x2 *)out;
     for (;;) {
         const bool live = r < end;
         const uint64_t active = __ballot(live);
@@ -106,7 +120,7 @@ __device__ __forceinline__ void run_lane_streams(const uint16_t *__restrict__ in
         const uint32_t stop = live ? min(end, base + 256u) : r;
         for (int l0 = 0; l0 < 64; l0 += 8) {                 // ---- load windows
             if (((active >> l0) & 0xFFull) == 0ull) continue;
-            uint2 tmp[8];
+            u32x2 tmp[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) tmp[u] = in_w[(read_lane(base, l0 + u) >> 2) + lane];
 #pragma unroll
@@ -118,14 +132,14 @@ __device__ __forceinline__ void run_lane_streams(const uint16_t *__restrict__ in
             const bool mine = live && wi * 4 + 3 >= c0 && wi * 4 < c1;
             if (__ballot(mine) == 0ull) continue;
             if (mine) {
-                uint2 w = stage[lane * kRowWords + wi];
+                u32x2 w = stage[lane * kRowWords + wi];
                 uint32_t rec[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int col = wi * 4 + k;
                     if (col >= c0 && col < c1) rec[k] = step(rec[k]) & 0xFFFFu;
                 }
-                stage[lane * kRowWords + wi] = make_uint2(rec[0] | (rec[1] << 16), rec[2] | (rec[3] << 16));
+                stage[lane * kRowWords + wi] = u32x2{rec[0] | (rec[1] << 16), rec[2] | (rec[3] << 16)};
             }
         }
         __syncthreads();
@@ -134,7 +148,7 @@ __device__ __forceinline__ void run_lane_streams(const uint16_t *__restrict__ in
             const uint32_t b = read_lane(base, l), lo = read_lane(r, l), hi = read_lane(stop, l);
             const uint32_t idx = b + uint32_t(lane) * 4u;
             if (idx + 4u <= lo || idx >= hi) continue;
-            const uint2 w = stage[l * kRowWords + lane];
+            const u32x2 w = stage[l * kRowWords + lane];
             if (idx >= lo && idx + 4u <= hi) {
                 out_w[idx >> 2] = w;
             } else {                                         // window edge: only this stream's records
@@ -160,7 +174,7 @@ __global__ void __launch_bounds__(256) k_predict(const E1Job *__restrict__ jobs)
     int j = int(blockIdx.x) * 256 + int(threadIdx.x);
     int i = int(blockIdx.y);
     if (i >= J.h || j >= w) return;
-    const uint8_t *__restrict__ img = J.b.img;
+    const auto img = gptr(J.b.img);
     auto pix = [&](int r, int c) { return int(img[size_t(r) * size_t(w) + size_t(c)]); };
     Taps n = sample_taps(pix, w, i, j);
     int px0 = predict(n);
@@ -170,7 +184,7 @@ __global__ void __launch_bounds__(256) k_predict(const E1Job *__restrict__ jobs)
         err_prev = clip_err(n.a, predict(m));
     }
     Level L = quantise(activity(n, err_prev));
-    J.b.rec1[size_t(i) * size_t(w) + size_t(j)] = pack_s1(px0, context_address(n, L.qu, px0), L);
+    gptr(J.b.rec1)[size_t(i) * size_t(w) + size_t(j)] = pack_s1(px0, context_address(n, L.qu, px0), L);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -187,7 +201,7 @@ __device__ __forceinline__ void lds_fill(uint32_t *slice, uint32_t v) {
 __global__ void __launch_bounds__(256) k_adr_count(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][kContexts];
     const E1Job &J = jobs[blockIdx.y];
-    const uint32_t *__restrict__ rec1 = J.b.rec1; uint32_t *__restrict__ table = J.b.table;
+    const auto rec1 = gptr(J.b.rec1); const auto table = gptr(J.b.table);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
@@ -204,8 +218,8 @@ __global__ void __launch_bounds__(256) k_adr_count(const E1Job *__restrict__ job
 __global__ void __launch_bounds__(256) k_adr_scatter(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][kContexts];
     const E1Job &J = jobs[blockIdx.y];
-    const uint32_t *__restrict__ rec1 = J.b.rec1; const uint8_t *__restrict__ x = J.b.img;
-    const uint32_t *__restrict__ table = J.b.table; uint16_t *__restrict__ s2in = J.b.s2in; uint32_t *__restrict__ pos2 = J.b.pos2;
+    const auto rec1 = gptr(J.b.rec1); const auto x = gptr(J.b.img);
+    const auto table = gptr(J.b.table); const auto s2in = gptr(J.b.s2in); const auto pos2 = gptr(J.b.pos2);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
@@ -233,10 +247,10 @@ __global__ void __launch_bounds__(256) k_adr_scatter(const E1Job *__restrict__ j
 // state it held BEFORE that pixel: record in = err (low byte), record out = v >> 7, from which
 // the consumer rebuilds sign = out & 1 and px = clip(px0 + (out >> 1) + sign).
 __global__ void __launch_bounds__(64) k_bias_chains(const E1Job *__restrict__ jobs) {
-    __shared__ uint2 stage[64 * kRowWords];
+    __shared__ u32x2 stage[64 * kRowWords];
     const E1Job &J = jobs[blockIdx.y];
-    const uint16_t *__restrict__ s2in = J.b.s2in; const uint32_t *__restrict__ table = J.b.table;
-    int *__restrict__ ctx_state = J.b.ctx_state; uint16_t *__restrict__ s2out = J.b.s2out;
+    const auto s2in = gptr(J.b.s2in); const auto table = gptr(J.b.table);
+    const auto ctx_state = gptr(J.b.ctx_state); const auto s2out = gptr(J.b.s2out);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
     const int key = int(blockIdx.x) * 64 + int(threadIdx.x);
     const uint32_t start = table[size_t(key) * plan.nseg];
@@ -262,9 +276,9 @@ __device__ __forceinline__ bool mapper_item(int x, uint32_t ps, uint32_t &key, i
 __global__ void __launch_bounds__(256) k_map_count(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][512];
     const E1Job &J = jobs[blockIdx.y];
-    const uint8_t *__restrict__ x = J.b.img; const uint16_t *__restrict__ s2out = J.b.s2out;
-    const uint32_t *__restrict__ pos2 = J.b.pos2; uint16_t *__restrict__ pxs = J.b.pxs; uint32_t *__restrict__ table = J.b.table;
-    const uint32_t *__restrict__ rec1 = J.b.rec1;
+    const auto x = gptr(J.b.img); const auto s2out = gptr(J.b.s2out);
+    const auto pos2 = gptr(J.b.pos2); const auto pxs = gptr(J.b.pxs); const auto table = gptr(J.b.table);
+    const auto rec1 = gptr(J.b.rec1);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
@@ -288,8 +302,8 @@ __global__ void __launch_bounds__(256) k_map_count(const E1Job *__restrict__ job
 __global__ void __launch_bounds__(256) k_map_scatter(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][512];
     const E1Job &J = jobs[blockIdx.y];
-    const uint8_t *__restrict__ x = J.b.img; const uint16_t *__restrict__ pxs = J.b.pxs;
-    const uint32_t *__restrict__ table = J.b.table; uint16_t *__restrict__ s3in = J.b.s3in; uint32_t *__restrict__ pos3 = J.b.pos3;
+    const auto x = gptr(J.b.img); const auto pxs = gptr(J.b.pxs);
+    const auto table = gptr(J.b.table); const auto s3in = gptr(J.b.s3in); const auto pos3 = gptr(J.b.pos3);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
@@ -317,14 +331,14 @@ __global__ void __launch_bounds__(256) k_map_scatter(const E1Job *__restrict__ j
 // 64 lanes of a wave hit 64 different banks whatever entry each of them indexes.
 __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ jobs) {
     __shared__ int rank_of[kMapSyms][64], sym_at[kMapSyms][64], count[kMapSyms][64];
-    __shared__ uint2 stage[64 * kRowWords];
+    __shared__ u32x2 stage[64 * kRowWords];
     const E1Job &J = jobs[blockIdx.y];
-    const uint16_t *__restrict__ s3in = J.b.s3in; const uint32_t *__restrict__ table = J.b.table;
-    const uint32_t *__restrict__ total = J.b.totals + 1; int *__restrict__ map_state = J.b.map_state;
-    uint16_t *__restrict__ s3out = J.b.s3out; const SegPlan plan = J.pp;
+    const auto s3in = gptr(J.b.s3in); const auto table = gptr(J.b.table);
+    const auto total = gptr(J.b.totals) + 1; const auto map_state = gptr(J.b.map_state);
+    const auto s3out = gptr(J.b.s3out); const SegPlan plan = J.pp;
     const int lane = int(threadIdx.x);
     const int key = int(blockIdx.x) * 64 + lane;
-    int *st = map_state + size_t(key) * (3 * kMapSyms);
+    auto st = map_state + size_t(key) * (3 * kMapSyms);
     for (int k = 0; k < kMapSyms; k++) {
         rank_of[k][lane] = st[k]; sym_at[k][lane] = st[kMapSyms + k]; count[k][lane] = st[2 * kMapSyms + k];
     }
@@ -353,8 +367,8 @@ __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ 
 // ---- S4: binarisation (NBLIC.c:640-679); path depends on (qu,qv,qw,z) only ----------------
 __global__ void __launch_bounds__(256) k_count_bins(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
-    const uint32_t *__restrict__ rec1 = J.b.rec1; const uint16_t *__restrict__ s3out = J.b.s3out;
-    const uint32_t *__restrict__ pos3 = J.b.pos3; uint8_t *__restrict__ z = J.b.z; uint8_t *__restrict__ cnt = J.b.cnt;
+    const auto rec1 = gptr(J.b.rec1); const auto s3out = gptr(J.b.s3out);
+    const auto pos3 = gptr(J.b.pos3); const auto z = gptr(J.b.z); const auto cnt = gptr(J.b.cnt);
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= J.n) return;
     Level L = s1_level(rec1[t]);
@@ -368,12 +382,12 @@ __global__ void __launch_bounds__(256) k_count_bins(const E1Job *__restrict__ jo
 
 __global__ void __launch_bounds__(256) k_emit_bins(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
-    const uint32_t *__restrict__ rec1 = J.b.rec1; const uint8_t *__restrict__ z = J.b.z;
-    const uint32_t *__restrict__ ev_off = J.b.ev_off; uint32_t *__restrict__ events = J.b.events;
+    const auto rec1 = gptr(J.b.rec1); const auto z = gptr(J.b.z);
+    const auto ev_off = gptr(J.b.ev_off); const auto events = gptr(J.b.events);
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= J.n) return;
     Level L = s1_level(rec1[t]);
-    uint32_t *out = events + ev_off[t];
+    auto out = events + ev_off[t];
     walk_symbol(kMinKStep, L.qu, L.qv, int(z[t]), [&](int qu, int qv, int node, int bin) {
         *out++ = pack_event(qu, qv, node, L.qw, bin);
         return bin;
@@ -410,7 +424,7 @@ __device__ __forceinline__ Touch touch_of(uint32_t e, int parity) {
 __global__ void __launch_bounds__(256) k_touch_count(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][4096];
     const E1Job &J = jobs[blockIdx.y];
-    const uint32_t *__restrict__ events = J.b.events; uint32_t *__restrict__ table = J.b.table;
+    const auto events = gptr(J.b.events); const auto table = gptr(J.b.table);
     const uint32_t n_ev = J.n_ev; const SegPlan plan = J.pe;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
@@ -433,8 +447,8 @@ __global__ void __launch_bounds__(256) k_touch_count(const E1Job *__restrict__ j
 __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][4096];
     const E1Job &J = jobs[blockIdx.y];
-    const uint32_t *__restrict__ events = J.b.events; const uint32_t *__restrict__ table = J.b.table;
-    uint16_t *__restrict__ tin = J.b.tin; uint2 *__restrict__ tpos = reinterpret_cast<uint2 *>(J.b.tpos);
+    const auto events = gptr(J.b.events); const auto table = gptr(J.b.table);
+    const auto tin = gptr(J.b.tin); const auto tpos = (NB_GLOBAL u32x2 *)gptr(J.b.tpos);
     const uint32_t n_ev = J.n_ev; const SegPlan plan = J.pe;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
@@ -459,7 +473,7 @@ __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__
                 if (rank == 0) off[t.key] += uint32_t(__popcll(same));
             }
         }
-        if (r < hi) tpos[r] = make_uint2(pos_u, have_v ? pos_v : pos_u);
+        if (r < hi) tpos[r] = u32x2{pos_u, have_v ? pos_v : pos_u};
     }
 }
 
@@ -474,24 +488,29 @@ constexpr int kTpl = 8;                  // touches per lane per window
 
 __global__ void __launch_bounds__(64) k_counter_chains(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
-    const uint16_t *__restrict__ tin = J.b.tin; const uint32_t *__restrict__ table = J.b.table;
-    const uint32_t *__restrict__ total = J.b.totals + 3; int2 *__restrict__ cnt_state = reinterpret_cast<int2 *>(J.b.cnt_state);
-    uint16_t *__restrict__ tout = J.b.tout; const SegPlan plan = J.pe;
+    const auto tin = gptr(J.b.tin); const auto table = gptr(J.b.table);
+    const auto total = gptr(J.b.totals) + 3; const auto cnt_state = (NB_GLOBAL i32x2 *)gptr(J.b.cnt_state);
+    const auto tout = gptr(J.b.tout); const SegPlan plan = J.pe;
     const int key = int(blockIdx.x);
     const int lane = int(threadIdx.x);
     const uint32_t start = table[size_t(key) * plan.nseg];
     const uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * plan.nseg] : *total;
     if (start >= end) return;
-    const uint4 *in_w = reinterpret_cast<const uint4 *>(tin);
-    uint4 *out_w = reinterpret_cast<uint4 *>(tout);
-    int2 st = cnt_state[key];
+    const auto in_w = (NB_GLOBAL const u32x4 *)tin;
+    const auto out_w = (NB_GLOBAL u32x4 *)tout;
+    i32x2 st = cnt_state[key];
     int base_s = st.x + st.y, base_1 = st.y;                         // wave-uniform running state
     const uint32_t first_window = start & ~7u;
-    uint4 nxt = in_w[(first_window >> 3) + lane];
-    for (uint32_t window = first_window; window < end; window += 64u * kTpl) {
-        const uint4 w = nxt;
+    constexpr uint32_t kWin = 64u * kTpl;
+    // three windows in flight: the chain is serial, so its memory latency must be covered by depth
+    u32x4 n0 = in_w[(first_window >> 3) + lane], n1 = n0, n2 = n0;
+    if (first_window + kWin < end) n1 = in_w[((first_window + kWin) >> 3) + lane];
+    if (first_window + 2 * kWin < end) n2 = in_w[((first_window + 2 * kWin) >> 3) + lane];
+    for (uint32_t window = first_window; window < end; window += kWin) {
+        const u32x4 w = n0;
+        n0 = n1; n1 = n2;
         const uint32_t first = window + uint32_t(lane) * kTpl;
-        if (window + 64u * kTpl < end) nxt = in_w[((window + 64u * kTpl) >> 3) + lane];
+        if (window + 3 * kWin < end) n2 = in_w[((window + 3 * kWin) >> 3) + lane];
         const uint32_t pay[kTpl] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
         int tot[kTpl], one[kTpl], tex[kTpl], oex[kTpl];
         int lt = 0, lo = 0;
@@ -544,24 +563,24 @@ __global__ void __launch_bounds__(64) k_counter_chains(const E1Job *__restrict__
 #pragma unroll
         for (int k = 0; k < kTpl; k++) p[k] = prob_one(c1_pre[k], s_pre[k]);
         if (first >= start && first + kTpl <= end) {
-            out_w[first >> 3] = make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
+            out_w[first >> 3] = u32x4{p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16)};
         } else {
 #pragma unroll
             for (int k = 0; k < kTpl; k++) if (first + k >= start && first + k < end) tout[first + k] = uint16_t(p[k]);
         }
     }
-    if (lane == 0) cnt_state[key] = make_int2(base_s - base_1, base_1);
+    if (lane == 0) cnt_state[key] = i32x2{base_s - base_1, base_1};
 }
 
 // ---- mix the two trees' probabilities and pack for the host coder (NBLIC.c:629-633) -------
 __global__ void __launch_bounds__(256) k_mix(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
-    const uint32_t *__restrict__ events = J.b.events; const uint16_t *__restrict__ tout = J.b.tout;
-    const uint2 *__restrict__ tpos = reinterpret_cast<const uint2 *>(J.b.tpos); uint16_t *__restrict__ coded = J.b.coded;
+    const auto events = gptr(J.b.events); const auto tout = gptr(J.b.tout);
+    const auto tpos = (NB_GLOBAL const u32x2 *)gptr(J.b.tpos); const auto coded = gptr(J.b.coded);
     uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= J.n_ev) return;
     uint32_t e = events[r];
-    uint2 tp = tpos[r];
+    u32x2 tp = tpos[r];
     int qw = ev_qw(e);
     int pu = tout[tp.x], pv = tout[tp.y];
     coded[r] = pack_coded(mix_prob(pu, pv, qw), ev_bin(e));
@@ -570,10 +589,10 @@ __global__ void __launch_bounds__(256) k_mix(const E1Job *__restrict__ jobs) {
 // ---- model state init (NBLIC.c:797-804) ---------------------------------------------------
 __global__ void k_init_state(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
-    int *ctx_state = J.b.ctx_state, *map_state = J.b.map_state; int2 *cnt_state = reinterpret_cast<int2 *>(J.b.cnt_state);
+    const auto ctx_state = gptr(J.b.ctx_state); const auto map_state = gptr(J.b.map_state); const auto cnt_state = (NB_GLOBAL i32x2 *)gptr(J.b.cnt_state);
     int g = int(blockIdx.x) * 256 + int(threadIdx.x);
     if (g < kContexts) ctx_state[g] = 0;
-    if (g < 4096) cnt_state[g] = make_int2(kWeightOne, kWeightOne);
+    if (g < 4096) cnt_state[g] = i32x2{kWeightOne, kWeightOne};
     if (g < 512)
         for (int k = 0; k < kMapSyms; k++) {
             map_state[g * 60 + k] = k; map_state[g * 60 + 20 + k] = k; map_state[g * 60 + 40 + k] = 2 * (kMapSyms - 1 - k);
@@ -587,16 +606,16 @@ __global__ void k_init_state(const E1Job *__restrict__ jobs) {
 constexpr int kScanThreads = 256, kScanPerThread = 16, kScanTile = kScanThreads * kScanPerThread;
 
 template <int WHICH> struct ScanSel;
-template <> struct ScanSel<0> { typedef uint32_t T; static __device__ const T *in(const E1Job &J) { return J.b.table; }  static __device__ uint32_t *out(const E1Job &J) { return J.b.table; }  static __device__ uint32_t n(const E1Job &J) { return uint32_t(kContexts) * J.pp.nseg; } };
-template <> struct ScanSel<1> { typedef uint32_t T; static __device__ const T *in(const E1Job &J) { return J.b.table; }  static __device__ uint32_t *out(const E1Job &J) { return J.b.table; }  static __device__ uint32_t n(const E1Job &J) { return 512u * J.pp.nseg; } };
-template <> struct ScanSel<2> { typedef uint8_t  T; static __device__ const T *in(const E1Job &J) { return J.b.cnt; }    static __device__ uint32_t *out(const E1Job &J) { return J.b.ev_off; } static __device__ uint32_t n(const E1Job &J) { return J.n; } };
-template <> struct ScanSel<3> { typedef uint32_t T; static __device__ const T *in(const E1Job &J) { return J.b.table; }  static __device__ uint32_t *out(const E1Job &J) { return J.b.table; }  static __device__ uint32_t n(const E1Job &J) { return 4096u * J.pe.nseg; } };
+template <> struct ScanSel<0> { typedef uint32_t T; static __device__ auto in(const E1Job &J) { return gptr(J.b.table); }  static __device__ auto out(const E1Job &J) { return gptr(J.b.table); }  static __device__ uint32_t n(const E1Job &J) { return uint32_t(kContexts) * J.pp.nseg; } };
+template <> struct ScanSel<1> { typedef uint32_t T; static __device__ auto in(const E1Job &J) { return gptr(J.b.table); }  static __device__ auto out(const E1Job &J) { return gptr(J.b.table); }  static __device__ uint32_t n(const E1Job &J) { return 512u * J.pp.nseg; } };
+template <> struct ScanSel<2> { typedef uint8_t  T; static __device__ auto in(const E1Job &J) { return gptr(J.b.cnt); }    static __device__ auto out(const E1Job &J) { return gptr(J.b.ev_off); } static __device__ uint32_t n(const E1Job &J) { return J.n; } };
+template <> struct ScanSel<3> { typedef uint32_t T; static __device__ auto in(const E1Job &J) { return gptr(J.b.table); }  static __device__ auto out(const E1Job &J) { return gptr(J.b.table); }  static __device__ uint32_t n(const E1Job &J) { return 4096u * J.pe.nseg; } };
 
 template <int WHICH>
 __global__ void __launch_bounds__(kScanThreads) k_scan_reduce(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t part[kScanThreads / 64];
     const E1Job &J = jobs[blockIdx.y];
-    const typename ScanSel<WHICH>::T *in = ScanSel<WHICH>::in(J);
+    const auto in = ScanSel<WHICH>::in(J);
     const uint32_t n = ScanSel<WHICH>::n(J);
     uint32_t base = blockIdx.x * uint32_t(kScanTile) + threadIdx.x * kScanPerThread, s = 0;
     if (blockIdx.x * uint32_t(kScanTile) >= n) return;
@@ -604,7 +623,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_reduce(const E1Job *__res
     s = wave_scan_incl(s);
     if (lane_id() == 63) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) J.b.scan_sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) gptr(J.b.scan_sums)[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
 template <int WHICH>
@@ -612,7 +631,7 @@ __global__ void __launch_bounds__(1024) k_scan_sums(const E1Job *__restrict__ jo
     __shared__ uint32_t part[16];
     __shared__ uint32_t carry;
     const E1Job &J = jobs[blockIdx.y];
-    uint32_t *sums = J.b.scan_sums;
+    const auto sums = gptr(J.b.scan_sums);
     const uint32_t nblocks = (ScanSel<WHICH>::n(J) + kScanTile - 1) / kScanTile;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -629,15 +648,15 @@ __global__ void __launch_bounds__(1024) k_scan_sums(const E1Job *__restrict__ jo
         if (threadIdx.x == 1023) carry = pre + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) J.b.totals[WHICH] = carry;
+    if (threadIdx.x == 0) gptr(J.b.totals)[WHICH] = carry;
 }
 
 template <int WHICH>
 __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t part[kScanThreads / 64];
     const E1Job &J = jobs[blockIdx.y];
-    const typename ScanSel<WHICH>::T *in = ScanSel<WHICH>::in(J);     // may alias out (each thread re-writes its own items)
-    uint32_t *out = ScanSel<WHICH>::out(J);
+    const auto in = ScanSel<WHICH>::in(J);     // may alias out (each thread re-writes its own items)
+    const auto out = ScanSel<WHICH>::out(J);
     const uint32_t n = ScanSel<WHICH>::n(J);
     if (blockIdx.x * uint32_t(kScanTile) >= n) return;
     uint32_t base = blockIdx.x * uint32_t(kScanTile) + threadIdx.x * kScanPerThread;
@@ -646,7 +665,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const E1Job *__rest
     uint32_t incl = wave_scan_incl(s);
     if (lane_id() == 63) part[threadIdx.x >> 6] = incl;
     __syncthreads();
-    uint32_t pre = J.b.scan_sums[blockIdx.x] + incl - s;
+    uint32_t pre = gptr(J.b.scan_sums)[blockIdx.x] + incl - s;
     for (int wv = 0; wv < int(threadIdx.x >> 6); wv++) pre += part[wv];
     for (int k = 0; k < kScanPerThread; k++) { if (base + k < n) out[base + k] = pre; pre += v[k]; }
 }

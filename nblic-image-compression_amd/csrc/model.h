@@ -139,7 +139,8 @@ NB_HD int context_address(const Taps &n, int qu, int px0) {
 NB_HD int bias_sign(int v) { return (v >> (kCtxScale - 1)) & 1; }
 NB_HD int bias_apply(int v, int px0) { return iclip(px0 + (v >> kCtxScale) + bias_sign(v), 0, kMaxVal); }
 NB_HD int bias_update(int v, int err) {
-    return (v * ((1 << kCtxCoef) - 1) + err * (1 << kCtxScale) + (1 << (kCtxCoef - 1))) >> kCtxCoef;
+    // 127*v written as (v << 7) - v: a 32-bit integer multiply is a quarter-rate op on the chain's critical path
+    return (v * (1 << kCtxCoef) - v + err * (1 << kCtxScale) + (1 << (kCtxCoef - 1))) >> kCtxCoef;
 }
 NB_HD int clip_err(int x, int px0) { return iclip(x - px0, -(kMaxVal - kMid), kMaxVal - kMid); }
 

@@ -25,6 +25,8 @@
 #include "model.h"
 #include "serial_engine.h"
 
+struct nblic_amd_ctx;
+
 namespace nblic {
 
 #define HIP_OK(call)                                                                          \
@@ -128,6 +130,10 @@ struct Group {
     uint32_t *h_totals = nullptr, *d_totals = nullptr; // 4 words per slot
     int n_jobs = 0;
     int pending = 0;                                   // coder tasks outstanding (guarded by ctx->fm)
+    bool tm_pending = false;                           // timer events recorded, not yet read
+    ::nblic_amd_ctx *ctx = nullptr;
+    // the batch this group currently serves (valid from launch_back until its coders finish)
+    unsigned char *const *outs = nullptr; const size_t *caps = nullptr; long *lens = nullptr;
 };
 
 template <class T> static bool dev_alloc(T *&p, size_t count) {
@@ -156,13 +162,14 @@ struct nblic_amd_ctx {
     double stage_ms[kE1Kernels] = {0};
     long stage_launches = 0;
     double total_bins = 0, coder_s = 0;
+    std::mutex stat_m;
     SerialEngine serial;
 };
 
 namespace nblic {
 
-static bool group_init(Group &g, int id, int n_slots) {
-    g.id = id;
+static bool group_init(Group &g, int id, int n_slots, nblic_amd_ctx *c) {
+    g.id = id; g.ctx = c;
     g.slots.resize(size_t(n_slots));
     HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
@@ -245,7 +252,34 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
     return true;
 }
 
-static bool launch_back(nblic_amd_ctx *c, Group &g) {
+// Runs on a HIP runtime thread when the group's device->host copies have landed: hands every
+// image of the group to the coder threads.  (No HIP calls are allowed in here.)
+static void on_group_copied(void *vp) {
+    Group *gp = static_cast<Group *>(vp);
+    nblic_amd_ctx *c = gp->ctx;
+    for (int k = 0; k < gp->n_jobs; k++) {
+        Slot *sp = &gp->slots[size_t(k)];
+        c->pool->submit([c, sp, gp] {
+            Slot &s = *sp;
+            auto t0 = std::chrono::steady_clock::now();
+            const int job = s.job;
+            long len = -1;
+            if (gp->caps[job] >= size_t(kHeaderBytes) + 4) {
+                write_header(gp->outs[job], s.h, s.w, 0, kMinKStep, 1);
+                size_t body = range_code(s.h_coded, s.n_ev, gp->outs[job] + kHeaderBytes, gp->caps[job] - kHeaderBytes);
+                if (body != SIZE_MAX) len = long(kHeaderBytes + body);
+                else fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", job, gp->caps[job]);
+            }
+            gp->lens[job] = len;
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += double(s.n_ev); c->coder_s += dt; }
+            { std::lock_guard<std::mutex> l(c->fm); if (--gp->pending == 0) c->free_groups.push_back(gp->id); c->coding--; }
+            c->fcv.notify_all();
+        });
+    }
+}
+
+static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders) {
     HIP_OK(hipStreamSynchronize(g.stream));
     for (int k = 0; k < g.n_jobs; k++) {
         Slot &s = g.slots[size_t(k)];
@@ -257,16 +291,22 @@ static bool launch_back(nblic_amd_ctx *c, Group &g) {
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
     e1_launch_back(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);
+    g.tm_pending = c->timing;
     for (int k = 0; k < g.n_jobs; k++) {
         Slot &s = g.slots[size_t(k)];
         HIP_OK(hipMemcpyAsync(s.h_coded, s.b.coded, size_t(s.n_ev) * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
     }
-    HIP_OK(hipEventRecord(g.done, g.stream));
+    if (with_coders) {
+        { std::lock_guard<std::mutex> l(c->fm); g.pending = g.n_jobs; c->coding += g.n_jobs; }
+        HIP_OK(hipLaunchHostFunc(g.stream, on_group_copied, &g));
+    }
     return true;
 }
 
 static void collect_timing(nblic_amd_ctx *c, Group &g) {
-    if (!c->timing) return;
+    if (!g.tm_pending) return;
+    g.tm_pending = false;
+    if (hipEventSynchronize(g.tm.ev[kE1Kernels]) != hipSuccess) return;
     for (int k = 0; k < kE1Kernels; k++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g.tm.ev[k], g.tm.ev[k + 1]) == hipSuccess) c->stage_ms[k] += ms;
@@ -279,89 +319,46 @@ static void release_group(nblic_amd_ctx *c, int id) {
     c->fcv.notify_all();
 }
 
+// Groups are started one after the other: front half of group g+1 overlaps the back half of
+// group g on the GPU, and the host codes group g while the GPU is busy with g+1, g+2, ...
 static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *imgs, bool on_device, const int *hs,
                          const int *ws, uint8_t *const *outs, const size_t *caps, long *lens) {
     if (hipSetDevice(c->device) != hipSuccess) return false;
     for (auto &v : c->stage_ms) v = 0;
     c->stage_launches = 0;
     c->total_bins = 0; c->coder_s = 0;
-    std::mutex stat_m;
-    std::deque<int> p1, p2;
-    int next = 0;
     bool ok = true;
     for (int k = 0; k < n_images; k++) lens[k] = -1;
-
-    // hand every image of a finished group to the coder threads; the last one frees the group
-    auto submit_coders = [&](Group &g) {
-        collect_timing(c, g);
-        { std::lock_guard<std::mutex> l(c->fm); g.pending = g.n_jobs; c->coding += g.n_jobs; }
-        for (int k = 0; k < g.n_jobs; k++) {
-            Slot *sp = &g.slots[size_t(k)];
-            Group *gp = &g;
-            c->pool->submit([c, sp, gp, outs, caps, lens, &stat_m] {
-                Slot &s = *sp;
-                auto t0 = std::chrono::steady_clock::now();
-                const int job = s.job;
-                long len = -1;
-                if (caps[job] >= size_t(kHeaderBytes) + 4) {
-                    write_header(outs[job], s.h, s.w, 0, kMinKStep, 1);
-                    size_t body = range_code(s.h_coded, s.n_ev, outs[job] + kHeaderBytes, caps[job] - kHeaderBytes);
-                    if (body != SIZE_MAX) len = long(kHeaderBytes + body);
-                    else fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", job, caps[job]);
-                }
-                lens[job] = len;
-                double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                { std::lock_guard<std::mutex> l(stat_m); c->total_bins += double(s.n_ev); c->coder_s += dt; }
-                bool last;
-                { std::lock_guard<std::mutex> l(c->fm); last = --gp->pending == 0; c->coding--; if (last) c->free_groups.push_back(gp->id); }
-                c->fcv.notify_all();
-            });
-        }
-    };
-    auto try_acquire = [&](int &id) {
-        std::lock_guard<std::mutex> l(c->fm);
-        if (c->free_groups.empty()) return false;
-        id = c->free_groups.front(); c->free_groups.pop_front();
-        return true;
-    };
-    for (;;) {
+    int next = 0;
+    while (next < n_images) {
         int id;
-        while (next < n_images && try_acquire(id)) {
-            Group &g = c->groups[size_t(id)];
-            g.n_jobs = 0;
-            while (next < n_images && g.n_jobs < int(g.slots.size())) {
-                int k = next++;
-                if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; continue; }
-                Slot &s = g.slots[size_t(g.n_jobs++)];
-                s.job = k; s.h = hs[k]; s.w = ws[k];
-            }
-            if (g.n_jobs == 0) { release_group(c, id); continue; }
-            if (!launch_front(c, g, imgs, on_device)) { ok = false; hipStreamSynchronize(g.stream); release_group(c, id); continue; }
-            p1.push_back(id);
+        {
+            std::unique_lock<std::mutex> l(c->fm);
+            c->fcv.wait(l, [c] { return !c->free_groups.empty(); });
+            id = c->free_groups.front(); c->free_groups.pop_front();
         }
-        while (!p2.empty() && hipEventQuery(c->groups[size_t(p2.front())].done) == hipSuccess) {
-            submit_coders(c->groups[size_t(p2.front())]); p2.pop_front();
+        Group &g = c->groups[size_t(id)];
+        collect_timing(c, g);                               // events of its previous use are complete by now
+        g.outs = outs; g.caps = caps; g.lens = lens;
+        g.n_jobs = 0;
+        while (next < n_images && g.n_jobs < int(g.slots.size())) {
+            int k = next++;
+            if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; continue; }
+            Slot &s = g.slots[size_t(g.n_jobs++)];
+            s.job = k; s.h = hs[k]; s.w = ws[k];
         }
-        if (!p1.empty()) {
-            Group &g = c->groups[size_t(p1.front())]; p1.pop_front();
-            if (launch_back(c, g)) p2.push_back(g.id);
-            else { ok = false; hipStreamSynchronize(g.stream); release_group(c, g.id); }
-            continue;
+        if (g.n_jobs == 0) { release_group(c, id); continue; }
+        if (!launch_front(c, g, imgs, on_device) || !launch_back(c, g, true)) {
+            ok = false;
+            hipStreamSynchronize(g.stream);
+            release_group(c, id);
         }
-        if (!p2.empty()) {
-            Group &g = c->groups[size_t(p2.front())]; p2.pop_front();
-            if (hipEventSynchronize(g.done) != hipSuccess) { ok = false; release_group(c, g.id); continue; }
-            submit_coders(g);
-            continue;
-        }
-        if (next >= n_images) break;
-        std::unique_lock<std::mutex> l(c->fm);
-        c->fcv.wait(l, [c] { return !c->free_groups.empty(); });
     }
-    {   // wait for the coder threads
+    {   // wait for the coder threads (and with them every group's GPU work)
         std::unique_lock<std::mutex> l(c->fm);
         c->fcv.wait(l, [c] { return c->coding == 0; });
     }
+    for (auto &g : c->groups) collect_timing(c, g);
     for (int k = 0; k < n_images; k++) if (lens[k] < 0) ok = false;
     return ok;
 }
@@ -426,7 +423,7 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     c->device = device;
     c->groups.resize(size_t(n_groups));
     for (int i = 0; i < n_groups; i++) {
-        if (!group_init(c->groups[size_t(i)], i, group_size)) { nblic_amd_destroy(c); return nullptr; }
+        if (!group_init(c->groups[size_t(i)], i, group_size, c)) { nblic_amd_destroy(c); return nullptr; }
         c->free_groups.push_back(i);
     }
     if (!c->serial.init()) { nblic_amd_destroy(c); return nullptr; }
@@ -487,7 +484,8 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
     const uint8_t *imgs[1] = {img};
     long count = -1;
     size_t n = size_t(h) * size_t(w);
-    if (launch_front(c, grp, imgs, false) && launch_back(c, grp) && hipStreamSynchronize(grp.stream) == hipSuccess) {
+    if (launch_front(c, grp, imgs, false) && launch_back(c, grp, false) && hipStreamSynchronize(grp.stream) == hipSuccess) {
+        grp.tm_pending = false;
         const void *src = nullptr; size_t esz = 0, cnt = 0;
         switch (which) {
             case 0: src = s.b.rec1; esz = 4; cnt = n; break;
