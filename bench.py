@@ -49,12 +49,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--coders", type=int, default=0, help="host range-coder threads per GPU (0 = CPU share)")
     ap.add_argument("--slots", type=int, default=0, help="images in flight per GPU (0 = min(batch, 32))")
-    ap.add_argument("--groups", type=int, default=2, help="launch groups the images in flight are split into")
+    ap.add_argument("--groups", type=int, default=4, help="launch groups the images in flight are split into")
     ap.add_argument("--host-inputs", action="store_true", help="hand host buffers over (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

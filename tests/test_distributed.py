@@ -1,0 +1,62 @@
+"""CPU suite: the N > 1 path (one process per GPU, a single rooted gather of the finished
+streams) exercised with world_size 2 over gloo.  The same function runs over RCCL in bench.py."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _streams_for(rank, n):
+    rng = np.random.default_rng(100 + rank)
+    return [rng.integers(0, 256, int(rng.integers(0, 5000)), dtype=np.uint8).tobytes() for _ in range(n)]
+
+
+def _worker(rank, world, port, counts, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gather = importlib.import_module("nblic-image-compression_amd.gather")
+        mine = _streams_for(rank, counts[rank])
+        got = gather.gather_streams(mine, torch.device("cpu"))
+        if rank == 0:
+            ok = got is not None and len(got) == world
+            for r in range(world):
+                ok = ok and got[r] == _streams_for(r, counts[r])
+            q.put(bool(ok))
+        else:
+            assert got is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [(3, 3), (4, 1), (2, 0)])
+def test_gather_streams_world2_gloo(counts):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, counts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
+
+
+def test_pack_roundtrip():
+    gather = importlib.import_module("nblic-image-compression_amd.gather")
+    payload, lens = gather.pack([b"abc", b"", b"defgh"])
+    assert payload.tobytes() == b"abcdefgh" and lens.tolist() == [3, 0, 5]

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condenses a gpurun_out/prof_* directory (rocprofv3 --kernel-trace --stats run plus separate
+--pmc FETCH_SIZE / --pmc WRITE_SIZE runs of bench.py) into the small files kept under profiles/.
+
+    python tools/summarize_profile.py gpurun_out/prof_r1 profiles/r01
+"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+
+def pmc(dirname, counter):
+    files = glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            a = agg[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return {k: (n, v / n) for k, (n, v) in agg.items()}
+
+
+def main(src, dst):
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], dst + "_kernel_stats.csv")
+    for name in ("bench_plain.json", "bench_trace.json"):
+        p = os.path.join(src, name)
+        if os.path.exists(p):
+            shutil.copy(p, dst + "_" + name)
+    fetch, write = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE"), pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    with open(dst + "_hbm_traffic.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "FETCH_SIZE_KB_per_launch_raw", "WRITE_SIZE_KB_per_launch", "hbm_MB_per_launch_corrected(2*fetch+write)"])
+        for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, (0, 0))[1] + write.get(k, (0, 0))[1])):
+            fn, fv = fetch.get(k, (0, 0.0))
+            wn, wv = write.get(k, (0, 0.0))
+            w.writerow([k, max(fn, wn), round(fv, 1), round(wv, 1), round((2 * fv + wv) / 1024, 1)])
+    print("wrote", dst + "_*")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
