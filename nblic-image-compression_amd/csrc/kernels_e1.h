@@ -37,6 +37,11 @@ struct E1Buffers {
     uint16_t *tin;           // 2*ev_cap+pad  touch payloads grouped by counter
     uint64_t *tpos;          // ev_cap        {position of the tree-u touch, of the tree-v touch}
     uint16_t *tout;          // 2*ev_cap+pad  P(bin==1) before each touch, same order as tin
+    uint32_t *blk_base;      // 2049          first block of every context chain (+ total)
+    int      *blk_end;       // n/4096+2048   context state at the end of each block
+    uint8_t  *blk_ok;        // n/4096+2048   1 = the block's warm-up copies met (its output is exact)
+    uint32_t *win_base;      // 4097          first window record of every counter chain (+ total)
+    uint32_t *win_recs;      // 24 words per 512-touch window: entry state + halving epochs (kernels_e1.hip WinRec)
     uint16_t *coded;         // ev_cap        prob | bin<<15 for the host range coder
 };
 
@@ -49,25 +54,26 @@ struct E1Job {
     SegPlan pp;          // partition plan over pixels
     uint32_t n_ev;       // bins (known after the front half)
     SegPlan pe;          // partition plan over bins
+    int dbg;             // timing experiments only (NBLIC_AMD_DBG); 0 in normal operation
 };
 
 // One HIP event before every kernel launch (and one after the last): interval k is exactly
 // launch k of the sequence below, measured on the stream it runs on.  A launch covers the
 // whole group of images.
-constexpr int kE1Kernels = 27;
+constexpr int kE1Kernels = 31;
 constexpr int kE1Marks = kE1Kernels + 1;
 struct E1Timers { hipEvent_t ev[kE1Marks]; };
 static const char *const kE1StageNames[kE1Kernels] = {
     "k_init_state", "k_predict",
     "k_adr_count", "scan_reduce.adr", "scan_sums.adr", "scan_apply.adr", "k_adr_scatter",
-    "k_bias_chains",
+    "k_plan_blocks", "k_bias_blocks", "k_bias_fixup",
     "k_map_count", "scan_reduce.map", "scan_sums.map", "scan_apply.map", "k_map_scatter",
     "k_mapper_chains",
     "k_count_bins", "scan_reduce.bins", "scan_sums.bins", "scan_apply.bins",
     "host_gap",
     "k_emit_bins",
     "k_touch_count", "scan_reduce.touch", "scan_sums.touch", "scan_apply.touch", "k_touch_scatter",
-    "k_counter_chains",
+    "k_plan_windows", "k_counter_epochs", "k_counter_probs",
     "k_mix"};
 
 int e1_selftest(hipStream_t s);     // 0 = DPP wave scan agrees with the shuffle scan

@@ -99,37 +99,45 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) { return uint32
 
 // Lane-per-key streaming: each of the wave's 64 lanes owns one run of 2-byte records
 // in[r .. end) and must replace every record by step(record) in order.  Per round the wave
-// stages, for each live stream, the aligned 512-byte window that holds its next records with
-// ONE coalesced request (64 lanes x 8 B of the same stream), every lane then walks its own LDS
-// row in place, and the windows are written back the same way.  Rows are padded to 65 words so
-// the walk (all lanes on the same column of different rows) is bank-conflict free.
-// Arrays must be padded by 512 B: a window may extend past the last record.
+// stages, for each stream, the aligned 512-byte window that holds its next records with ONE
+// coalesced request (64 lanes x 8 B of the same stream), every lane then walks its own LDS row
+// in place, and the windows are written back the same way.  All 64 requests of the NEXT round
+// are in flight (128 VGPRs) while the current round is walked, so the serial walk never waits on
+// HBM.  Rows are padded to 65 words so the walk (all lanes on the same column of different
+// rows) is bank-conflict free.  Arrays must be padded by 512 B: a window may extend past the
+// last record, and finished streams keep re-reading their last window.  Records before
+// `out_from` are walked (warm-up) but never written back.
 constexpr int kRowWords = 65;
 
 template <class StepFn>
 __device__ __forceinline__ void run_lane_streams(NB_GLOBAL const uint16_t *in, NB_GLOBAL uint16_t *out, uint32_t r,
-                                                 const uint32_t end, u32x2 *stage, StepFn step) {
+                                                 const uint32_t end, const uint32_t out_from, u32x2 *stage, StepFn step) {
     const int lane = lane_id();
     const auto in_w = (NB_GLOBAL const u32x2 *)in;
     const auto out_w = (NB_GLOBAL u32x2 *)out;
+    bool live = r < end;
+    uint64_t active = __ballot(live);
+    if (active == 0ull) return;
+    uint32_t base = r & ~3u;                                 // window = records [base, base + 256)
+    u32x2 regs[64];
+#pragma unroll
+    for (int l = 0; l < 64; l++) regs[l] = in_w[(read_lane(base, l) >> 2) + lane];
     for (;;) {
-        const bool live = r < end;
-        const uint64_t active = __ballot(live);
-        if (active == 0ull) break;
-        const uint32_t base = r & ~3u;                       // window = records [base, base + 256)
-        const uint32_t stop = live ? min(end, base + 256u) : r;
-        for (int l0 = 0; l0 < 64; l0 += 8) {                 // ---- load windows
-            if (((active >> l0) & 0xFFull) == 0ull) continue;
-            u32x2 tmp[8];
+        const uint32_t cur_r = r, cur_base = base;
+        const uint32_t cur_stop = live ? min(end, base + 256u) : r;
+        const uint64_t cur_active = active;
+        const bool cur_live = live;
 #pragma unroll
-            for (int u = 0; u < 8; u++) tmp[u] = in_w[(read_lane(base, l0 + u) >> 2) + lane];
-#pragma unroll
-            for (int u = 0; u < 8; u++) stage[(l0 + u) * kRowWords + lane] = tmp[u];
-        }
+        for (int l = 0; l < 64; l++) stage[l * kRowWords + lane] = regs[l];
         __syncthreads();
-        const int c0 = int(r - base), c1 = int(stop - base); // ---- walk own row: columns [c0, c1)
+        r = cur_stop; live = r < end; active = __ballot(live); base = r & ~3u;
+        if (active != 0ull) {                                // next round's windows: issue now, use after the walk
+#pragma unroll
+            for (int l = 0; l < 64; l++) regs[l] = in_w[(read_lane(base, l) >> 2) + lane];
+        }
+        const int c0 = int(cur_r - cur_base), c1 = int(cur_stop - cur_base);   // ---- walk own row: columns [c0, c1)
         for (int wi = 0; wi < 64; wi++) {
-            const bool mine = live && wi * 4 + 3 >= c0 && wi * 4 < c1;
+            const bool mine = cur_live && wi * 4 + 3 >= c0 && wi * 4 < c1;
             if (__ballot(mine) == 0ull) continue;
             if (mine) {
                 u32x2 w = stage[lane * kRowWords + wi];
@@ -137,15 +145,15 @@ __device__ __forceinline__ void run_lane_streams(NB_GLOBAL const uint16_t *in, N
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int col = wi * 4 + k;
-                    if (col >= c0 && col < c1) rec[k] = step(rec[k]) & 0xFFFFu;
+                    if (col >= c0 && col < c1) rec[k] = step(rec[k], cur_base + uint32_t(col)) & 0xFFFFu;
                 }
                 stage[lane * kRowWords + wi] = u32x2{rec[0] | (rec[1] << 16), rec[2] | (rec[3] << 16)};
             }
         }
         __syncthreads();
         for (int l = 0; l < 64; l++) {                       // ---- write windows back
-            if (((active >> l) & 1ull) == 0ull) continue;
-            const uint32_t b = read_lane(base, l), lo = read_lane(r, l), hi = read_lane(stop, l);
+            if (((cur_active >> l) & 1ull) == 0ull) continue;
+            const uint32_t b = read_lane(cur_base, l), lo = max(read_lane(cur_r, l), read_lane(out_from, l)), hi = read_lane(cur_stop, l);
             const uint32_t idx = b + uint32_t(lane) * 4u;
             if (idx + 4u <= lo || idx >= hi) continue;
             const u32x2 w = stage[l * kRowWords + lane];
@@ -157,8 +165,8 @@ __device__ __forceinline__ void run_lane_streams(NB_GLOBAL const uint16_t *in, N
                 for (int k = 0; k < 4; k++) if (idx + k >= lo && idx + k < hi) out[idx + k] = uint16_t(rec[k]);
             }
         }
-        r = stop;
         __syncthreads();
+        if (active == 0ull) break;
     }
 }
 
@@ -242,26 +250,106 @@ __global__ void __launch_bounds__(256) k_adr_scatter(const E1Job *__restrict__ j
     }
 }
 
-// ---- S2: context-bias chains, one lane per context (NBLIC.c:413-428) ---------------------
+// ---- S2: context-bias chains (NBLIC.c:413-428), parallel in TIME by monotone coupling -------
 // The chain itself only needs the clipped error of each pixel and only has to publish the
 // state it held BEFORE that pixel: record in = err (low byte), record out = v >> 7, from which
 // the consumer rebuilds sign = out & 1 and px = clip(px0 + (out >> 1) + sign).
-__global__ void __launch_bounds__(64) k_bias_chains(const E1Job *__restrict__ jobs) {
+//
+// v' = (127 v + 256 e + 64) >> 7 is non-decreasing in v and |v| <= 32576.  So if two copies
+// started from -32576 and +32576 are fed the same errors and meet, every possible start has met
+// them: the state is known EXACTLY without knowing where it came from.  On image data they meet
+// within ~2100 records (the error dithers the floor).  Each chain is therefore cut into blocks
+// of kBiasBlock records; a lane warms both copies up over the kBiasWarm records before its
+// block, takes the common state if they met, and replays its block.  Blocks whose copies did
+// not meet (flat regions: a constant error parks them 127 apart) are replayed afterwards from
+// their predecessor's end state by k_bias_fixup, in order -- still exact, just serial.
+constexpr uint32_t kBiasBlock = 4096, kBiasWarm = 3072;
+constexpr int kBiasExtreme = 32576;
+
+// blocks per chain -> exclusive scan -> blk_base[2049]; one 1024-thread block per job
+__global__ void __launch_bounds__(1024) k_plan_blocks(const E1Job *__restrict__ jobs) {
+    __shared__ uint32_t part[16];
+    const E1Job &J = jobs[blockIdx.y];
+    const auto table = gptr(J.b.table); const auto blk_base = gptr(J.b.blk_base);
+    const int nseg = J.pp.nseg;
+    uint32_t cnt[2], sum = 0;
+    for (int k = 0; k < 2; k++) {
+        int key = int(threadIdx.x) * 2 + k;
+        uint32_t start = table[size_t(key) * nseg];
+        uint32_t end = key + 1 < kContexts ? table[size_t(key + 1) * nseg] : J.n;
+        cnt[k] = (end - start + kBiasBlock - 1) / kBiasBlock;
+        sum += cnt[k];
+    }
+    uint32_t incl = wave_scan_incl(sum);
+    if (lane_id() == 63) part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t pre = incl - sum;
+    for (int wv = 0; wv < int(threadIdx.x >> 6); wv++) pre += part[wv];
+    for (int k = 0; k < 2; k++) { blk_base[threadIdx.x * 2 + k] = pre; pre += cnt[k]; }
+    if (threadIdx.x == 1023) blk_base[kContexts] = pre;
+}
+
+// one LANE per block of any chain; grid.x is an upper bound on the block count
+__global__ void __launch_bounds__(64) k_bias_blocks(const E1Job *__restrict__ jobs) {
     __shared__ u32x2 stage[64 * kRowWords];
     const E1Job &J = jobs[blockIdx.y];
-    const auto s2in = gptr(J.b.s2in); const auto table = gptr(J.b.table);
-    const auto ctx_state = gptr(J.b.ctx_state); const auto s2out = gptr(J.b.s2out);
-    const uint32_t n = J.n; const SegPlan plan = J.pp;
-    const int key = int(blockIdx.x) * 64 + int(threadIdx.x);
-    const uint32_t start = table[size_t(key) * plan.nseg];
-    const uint32_t end = key + 1 < kContexts ? table[size_t(key + 1) * plan.nseg] : n;
-    int v = ctx_state[key];
-    run_lane_streams(s2in, s2out, start, end, stage, [&](uint32_t rec) {
-        uint32_t o = uint32_t(v >> (kCtxScale - 1));
-        v = bias_update(v, int(int8_t(rec)));
+    const auto s2in = gptr(J.b.s2in); const auto s2out = gptr(J.b.s2out); const auto table = gptr(J.b.table);
+    const auto blk_base = gptr(J.b.blk_base); const auto blk_end = gptr(J.b.blk_end);
+    const uint32_t n_items = blk_base[kContexts];
+    const uint32_t item = blockIdx.x * 64u + threadIdx.x;
+    if (blockIdx.x * 64u >= n_items) return;                          // whole wave idle
+    const bool have = item < n_items;
+    // which chain?  largest key with blk_base[key] <= item
+    int key = 0;
+    if (have) {
+        int lo = 0, hi = kContexts;                                   // invariant: blk_base[lo] <= item < blk_base[hi]
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (blk_base[mid] <= item) lo = mid; else hi = mid; }
+        key = lo;
+    }
+    const int nseg = J.pp.nseg;
+    const uint32_t c_start = table[size_t(key) * nseg];
+    const uint32_t c_end = key + 1 < kContexts ? table[size_t(key + 1) * nseg] : J.n;
+    const uint32_t blk = have ? item - blk_base[key] : 0u;
+    const uint32_t b_start = c_start + blk * kBiasBlock;
+    const uint32_t b_end = have ? min(c_end, b_start + kBiasBlock) : 0u;
+    const uint32_t w_start = (blk == 0u || b_start - c_start <= kBiasWarm) ? c_start : b_start - kBiasWarm;
+    // warming up from the chain's own first record starts from its true state: both copies equal
+    const bool exact = w_start == c_start;
+    const int v0 = gptr(J.b.ctx_state)[key];
+    int va = exact ? v0 : -kBiasExtreme, vb = exact ? v0 : kBiasExtreme;
+    bool met = false;
+    run_lane_streams(s2in, s2out, have ? w_start : 0u, b_end, b_start, stage, [&](uint32_t rec, uint32_t idx) {
+        const int e = int(int8_t(rec));
+        if (idx == b_start) met = va == vb;                           // did the two copies meet during the warm-up?
+        uint32_t o = uint32_t(va >> (kCtxScale - 1));
+        va = bias_update(va, e);
+        if (idx < b_start) vb = bias_update(vb, e);                   // warm-up: carry the second copy too
         return o;
     });
-    ctx_state[key] = v;
+    if (have) { blk_end[item] = va; gptr(J.b.blk_ok)[item] = uint8_t(met); }
+}
+
+// one lane per chain: replays, in order, the blocks whose warm-up did not meet; publishes the final state
+__global__ void __launch_bounds__(64) k_bias_fixup(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.y];
+    const auto s2in = gptr(J.b.s2in); const auto s2out = gptr(J.b.s2out); const auto table = gptr(J.b.table);
+    const auto blk_base = gptr(J.b.blk_base); const auto blk_end = gptr(J.b.blk_end); const auto blk_ok = gptr(J.b.blk_ok);
+    const int key = int(blockIdx.x) * 64 + int(threadIdx.x);
+    const int nseg = J.pp.nseg;
+    const uint32_t c_start = table[size_t(key) * nseg];
+    const uint32_t c_end = key + 1 < kContexts ? table[size_t(key + 1) * nseg] : J.n;
+    const uint32_t first = blk_base[key], count = blk_base[key + 1] - first;
+    int v = gptr(J.b.ctx_state)[key];
+    for (uint32_t b = 0; b < count; b++) {
+        if (blk_ok[first + b]) { v = blk_end[first + b]; continue; }
+        const uint32_t lo = c_start + b * kBiasBlock, hi = min(c_end, lo + kBiasBlock);
+        for (uint32_t r = lo; r < hi; r++) {
+            s2out[r] = uint16_t(v >> (kCtxScale - 1));
+            v = bias_update(v, int(int8_t(s2in[r])));
+        }
+        blk_end[first + b] = v;
+    }
+    gptr(J.b.ctx_state)[key] = v;
 }
 
 // ---- partition 2: pixels by (px, sign) (512 keys); symbols >= 20 bypass the re-mapper -----
@@ -344,7 +432,7 @@ __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ 
     }
     const uint32_t start = table[size_t(key) * plan.nseg];
     const uint32_t end = key + 1 < 512 ? table[size_t(key + 1) * plan.nseg] : *total;
-    run_lane_streams(s3in, s3out, start, end, stage, [&](uint32_t y) {
+    run_lane_streams(s3in, s3out, start, end, start, stage, [&](uint32_t y, uint32_t) {
         int zz = rank_of[y][lane];
         int c = count[zz][lane] + 1;
         count[zz][lane] = c;
@@ -477,99 +565,190 @@ __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__
     }
 }
 
-// ---- S5: counter chains, one wave per counter (NBLIC.c:589-637) ---------------------------
+// ---- S5: counter chains (NBLIC.c:589-637) --------------------------------------------------
 // Between two halvings a counter is a pure running sum, and a halving needs the sum to climb
-// from <= 4129 past 8192 in steps <= 32, i.e. >= 127 touches.  Each iteration takes a 512-touch
-// aligned window (one 16-byte load per lane = 8 consecutive touches, next window prefetched),
-// prefix-sums the weights on the DPP crossbar and resolves the halvings that fall in the
-// window one epoch at a time; every other touch is plain arithmetic on its prefix.  Output is
-// P(bin==1) of the touched counter BEFORE the touch, written back as one 16-byte store per lane.
+// from <= 4129 past 8192 in steps <= 32, i.e. >= 127 touches.  The work is split in two:
+//
+//   k_counter_epochs  the SERIAL part, one wave per counter chain.  Walks the chain in aligned
+//                     512-touch windows (one 16-byte load per lane, three windows in flight),
+//                     prefix-sums the weights on the DPP crossbar and resolves only the halvings:
+//                     per window it records the state at entry and, for each halving inside, where
+//                     the next epoch starts and from which state.  No division, no per-touch output.
+//   k_counter_probs   the PARALLEL part, one wave per window of any chain.  Rebuilds the prefix,
+//                     picks each touch's epoch from the record and writes P(bin==1) before the touch.
 constexpr int kTpl = 8;                  // touches per lane per window
+constexpr uint32_t kWin = 64u * kTpl;    // touches per window
+constexpr int kMaxHalv = 5;              // halvings that fit in one window (>= 127 touches apart)
 
-__global__ void __launch_bounds__(64) k_counter_chains(const E1Job *__restrict__ jobs) {
+struct WinRec {                          // 24 words
+    uint32_t first, start, end;          // window's first touch slot (multiple of 8); chain's [start, end)
+    int vb_s, vb_1, n_halv;              // virtual base at entry: state before touch j = vb + exclusive prefix(j)
+    int from[kMaxHalv + 1], hs[kMaxHalv + 1], h1[kMaxHalv + 1];
+};
+static_assert(sizeof(WinRec) == 96, "WinRec is read as six 16-byte words");
+
+__device__ __forceinline__ void unpack_window(const u32x4 w, uint32_t first, uint32_t start, uint32_t end,
+                                              uint32_t (&pay)[kTpl], int (&tot)[kTpl], int (&one)[kTpl],
+                                              int (&tex)[kTpl], int (&oex)[kTpl], int &lt, int &lo) {
+    const uint32_t p[kTpl] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+    lt = 0; lo = 0;
+#pragma unroll
+    for (int k = 0; k < kTpl; k++) {
+        const bool ok = first + k >= start && first + k < end;
+        pay[k] = p[k];
+        tot[k] = ok ? int(p[k] & 63) + int((p[k] >> 6) & 63) : 0;
+        one[k] = ((p[k] >> 12) & 1) ? tot[k] : 0;
+        tex[k] = lt; oex[k] = lo; lt += tot[k]; lo += one[k];
+    }
+}
+
+// windows per chain -> exclusive scan -> win_base[4097]; one 1024-thread block per job
+__global__ void __launch_bounds__(1024) k_plan_windows(const E1Job *__restrict__ jobs) {
+    __shared__ uint32_t part[16];
+    const E1Job &J = jobs[blockIdx.y];
+    const auto table = gptr(J.b.table); const auto win_base = gptr(J.b.win_base);
+    const uint32_t total = gptr(J.b.totals)[3];
+    const int nseg = J.pe.nseg;
+    uint32_t cnt[4], sum = 0;
+    for (int k = 0; k < 4; k++) {
+        int key = int(threadIdx.x) * 4 + k;
+        uint32_t start = table[size_t(key) * nseg];
+        uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * nseg] : total;
+        cnt[k] = end > start ? (end - (start & ~7u) + kWin - 1) / kWin : 0u;
+        sum += cnt[k];
+    }
+    uint32_t incl = wave_scan_incl(sum);
+    if (lane_id() == 63) part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t pre = incl - sum;
+    for (int wv = 0; wv < int(threadIdx.x >> 6); wv++) pre += part[wv];
+    for (int k = 0; k < 4; k++) { win_base[threadIdx.x * 4 + k] = pre; pre += cnt[k]; }
+    if (threadIdx.x == 1023) win_base[4096] = pre;
+}
+
+__global__ void __launch_bounds__(64) k_counter_epochs(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
     const auto tin = gptr(J.b.tin); const auto table = gptr(J.b.table);
-    const auto total = gptr(J.b.totals) + 3; const auto cnt_state = (NB_GLOBAL i32x2 *)gptr(J.b.cnt_state);
-    const auto tout = gptr(J.b.tout); const SegPlan plan = J.pe;
+    const auto cnt_state = (NB_GLOBAL i32x2 *)gptr(J.b.cnt_state);
+    const auto recs = (NB_GLOBAL u32x4 *)gptr(J.b.win_recs);
+    const SegPlan plan = J.pe;
     const int key = int(blockIdx.x);
     const int lane = int(threadIdx.x);
     const uint32_t start = table[size_t(key) * plan.nseg];
-    const uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * plan.nseg] : *total;
+    const uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * plan.nseg] : gptr(J.b.totals)[3];
     if (start >= end) return;
     const auto in_w = (NB_GLOBAL const u32x4 *)tin;
-    const auto out_w = (NB_GLOBAL u32x4 *)tout;
+    uint32_t rec_i = gptr(J.b.win_base)[key];
     i32x2 st = cnt_state[key];
     int base_s = st.x + st.y, base_1 = st.y;                         // wave-uniform running state
+    const int dbg = J.dbg;
     const uint32_t first_window = start & ~7u;
-    constexpr uint32_t kWin = 64u * kTpl;
-    // three windows in flight: the chain is serial, so its memory latency must be covered by depth
-    u32x4 n0 = in_w[(first_window >> 3) + lane], n1 = n0, n2 = n0;
-    if (first_window + kWin < end) n1 = in_w[((first_window + kWin) >> 3) + lane];
-    if (first_window + 2 * kWin < end) n2 = in_w[((first_window + 2 * kWin) >> 3) + lane];
-    for (uint32_t window = first_window; window < end; window += kWin) {
-        const u32x4 w = n0;
-        n0 = n1; n1 = n2;
+    // Three windows in flight: the chain is serial, so its memory latency must be covered by
+    // depth.  The loop is unrolled by three over NAMED buffers -- rotating one register set at the
+    // back edge makes the compiler wait for the load it has only just issued.
+    auto process = [&](const u32x4 w, const uint32_t window) {
         const uint32_t first = window + uint32_t(lane) * kTpl;
-        if (window + 3 * kWin < end) n2 = in_w[((window + 3 * kWin) >> 3) + lane];
-        const uint32_t pay[kTpl] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
-        int tot[kTpl], one[kTpl], tex[kTpl], oex[kTpl];
-        int lt = 0, lo = 0;
-#pragma unroll
-        for (int k = 0; k < kTpl; k++) {
-            const bool ok = first + k >= start && first + k < end;
-            tot[k] = ok ? int(pay[k] & 63) + int((pay[k] >> 6) & 63) : 0;
-            one[k] = ((pay[k] >> 12) & 1) ? tot[k] : 0;
-            tex[k] = lt; oex[k] = lo; lt += tot[k]; lo += one[k];
-        }
-        uint32_t incl = wave_scan_incl_dpp((uint32_t(lt) << 16) | uint32_t(lo));
+        uint32_t pay[kTpl]; int tot[kTpl], one[kTpl], tex[kTpl], oex[kTpl], lt, lo;
+        unpack_window(w, first, start, end, pay, tot, one, tex, oex, lt, lo);
+        const uint32_t incl = wave_scan_incl_dpp((uint32_t(lt) << 16) | uint32_t(lo));
         const int lane_t = int(incl >> 16) - lt, lane_o = int(incl & 0xFFFF) - lo;    // exclusive over lanes
         const uint32_t last = read_lane(incl, 63);
-        const int win_t = int(last >> 16), win_o = int(last & 0xFFFF);
-        // virtual base: state before touch j of the current epoch = vb + exclusive prefix(j)
-        int vb_s = base_s + lane_t, vb_1 = base_1 + lane_o;         // per lane: lane offset folded in
-        int from = 0;                                               // first touch (window-relative) of the epoch
-        int s_pre[kTpl], c1_pre[kTpl];
+        int vb_s = base_s, vb_1 = base_1;                           // uniform virtual base of the current epoch
+        int from = 0, n_halv = 0;
+        int r_from[kMaxHalv + 1], r_s[kMaxHalv + 1], r_1[kMaxHalv + 1];
+#pragma unroll
+        for (int h = 0; h <= kMaxHalv; h++) { r_from[h] = 0x7FFFFFFF; r_s[h] = 0; r_1[h] = 0; }
+        const int entry_s = vb_s, entry_1 = vb_1;
+#pragma unroll 1
         for (;;) {
-            int trig = kTpl;
+            // which lane's touches push the sum over the limit first?
+            const uint64_t over = __ballot(lane * kTpl + kTpl - 1 >= from && vb_s + lane_t + lt > kCountLimit);
+            if (over == 0ull || n_halv > kMaxHalv || (dbg & 1)) break;
+            const int H = __ffsll((unsigned long long)over) - 1;
+            // every lane scans its own eight touches; only lane H's answer is read
+            int s_run = vb_s + lane_t, o_run = vb_1 + lane_o, s_at = 0, o_at = 0, k_at = kTpl;
+            uint32_t pay_at = 0;
 #pragma unroll
-            for (int k = kTpl - 1; k >= 0; k--) {
-                if (lane * kTpl + k >= from) {
-                    s_pre[k] = vb_s + tex[k]; c1_pre[k] = vb_1 + oex[k];
-                    if (s_pre[k] + tot[k] > kCountLimit) trig = k;
-                }
+            for (int k = 0; k < kTpl; k++) {
+                const bool hit = k_at == kTpl && lane * kTpl + k >= from && s_run + tot[k] > kCountLimit;
+                if (hit) { k_at = k; s_at = s_run; o_at = o_run; pay_at = pay[k]; }
+                s_run += tot[k]; o_run += one[k];
             }
-            uint64_t over = __ballot(trig < kTpl);
-            if (over == 0ull) break;
-            const int H = __ffsll((unsigned long long)over) - 1;    // first lane with a halving, uniform
-            const int hk = int(read_lane(uint32_t(trig), H));
-            int sel_s = s_pre[0], sel_1 = c1_pre[0], sel_tin = tex[0] + tot[0], sel_oin = oex[0] + one[0];
-            uint32_t sel_pay = pay[0];
-#pragma unroll
-            for (int k = 1; k < kTpl; k++)
-                if (hk == k) { sel_s = s_pre[k]; sel_1 = c1_pre[k]; sel_tin = tex[k] + tot[k]; sel_oin = oex[k] + one[k]; sel_pay = pay[k]; }
-            const int hs = int(read_lane(uint32_t(sel_s), H)), h1 = int(read_lane(uint32_t(sel_1), H));
-            const uint32_t hp = read_lane(sel_pay, H);
-            // inclusive prefix of the triggering touch, window-relative (lane offset of lane H included)
-            const int h_tin = int(read_lane(uint32_t(sel_tin + lane_t), H)), h_oin = int(read_lane(uint32_t(sel_oin + lane_o), H));
+            const int hk = int(read_lane(uint32_t(k_at), H));
+            const int hs = int(read_lane(uint32_t(s_at), H)), h1 = int(read_lane(uint32_t(o_at), H));
+            const uint32_t hp = read_lane(pay_at, H);
             Counter c{hs - h1, h1};
             const int hb = int((hp >> 12) & 1), hw1 = int(hp & 63), hw2 = int((hp >> 6) & 63);
             counter_add(c, hb, hw1);
             if (hw2) counter_add(c, hb, hw2);                       // state after the triggering touch
-            vb_s = c.c0 + c.c1 - h_tin + lane_t; vb_1 = c.c1 - h_oin + lane_o;
+            // inclusive prefix of the triggering touch = its pre-state minus the epoch base, plus its own weight
+            const int h_tin = hs - vb_s + hw1 + hw2, h_oin = h1 - vb_1 + (hb ? hw1 + hw2 : 0);
+            vb_s = c.c0 + c.c1 - h_tin; vb_1 = c.c1 - h_oin;
             from = H * kTpl + hk + 1;
-        }
-        base_s = int(read_lane(uint32_t(vb_s - lane_t), 0)) + win_t; base_1 = int(read_lane(uint32_t(vb_1 - lane_o), 0)) + win_o;
-        uint32_t p[kTpl];
 #pragma unroll
-        for (int k = 0; k < kTpl; k++) p[k] = prob_one(c1_pre[k], s_pre[k]);
-        if (first >= start && first + kTpl <= end) {
-            out_w[first >> 3] = u32x4{p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16)};
-        } else {
-#pragma unroll
-            for (int k = 0; k < kTpl; k++) if (first + k >= start && first + k < end) tout[first + k] = uint16_t(p[k]);
+            for (int h = 0; h <= kMaxHalv; h++) if (h == n_halv) { r_from[h] = from; r_s[h] = vb_s; r_1[h] = vb_1; }
+            n_halv++;
         }
+        base_s = vb_s + int(last >> 16); base_1 = vb_1 + int(last & 0xFFFF);
+        if (lane == 0 && !(dbg & 2)) {
+            const auto r = recs + size_t(rec_i) * 6;
+            r[0] = u32x4{window, start, end, uint32_t(entry_s)};
+            r[1] = u32x4{uint32_t(entry_1), uint32_t(n_halv), uint32_t(r_from[0]), uint32_t(r_from[1])};
+            r[2] = u32x4{uint32_t(r_from[2]), uint32_t(r_from[3]), uint32_t(r_from[4]), uint32_t(r_from[5])};
+            r[3] = u32x4{uint32_t(r_s[0]), uint32_t(r_s[1]), uint32_t(r_s[2]), uint32_t(r_s[3])};
+            r[4] = u32x4{uint32_t(r_s[4]), uint32_t(r_s[5]), uint32_t(r_1[0]), uint32_t(r_1[1])};
+            r[5] = u32x4{uint32_t(r_1[2]), uint32_t(r_1[3]), uint32_t(r_1[4]), uint32_t(r_1[5])};
+        }
+        rec_i++;
+    };
+    auto fetch = [&](uint32_t window) { return (window < end && !(dbg & 4)) ? in_w[(window >> 3) + lane] : u32x4{0x10101010u, 0x10101010u, 0x10101010u, 0x10101010u}; };
+    u32x4 b0 = fetch(first_window), b1 = fetch(first_window + kWin), b2 = fetch(first_window + 2 * kWin);
+    for (uint32_t window = first_window; window < end; window += 3 * kWin) {
+        process(b0, window);
+        b0 = fetch(window + 3 * kWin);
+        if (window + kWin < end) process(b1, window + kWin);
+        b1 = fetch(window + 4 * kWin);
+        if (window + 2 * kWin < end) process(b2, window + 2 * kWin);
+        b2 = fetch(window + 5 * kWin);
     }
     if (lane == 0) cnt_state[key] = i32x2{base_s - base_1, base_1};
+}
+
+// one wave per recorded window; grid.x is an upper bound, surplus waves leave at once
+__global__ void __launch_bounds__(256) k_counter_probs(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.y];
+    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= gptr(J.b.win_base)[4096]) return;
+    const int lane = lane_id();
+    const auto r = (NB_GLOBAL const u32x4 *)gptr(J.b.win_recs) + size_t(g) * 6;
+    const u32x4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+    const uint32_t window = r0.x, start = r0.y, end = r0.z;
+    const int n_halv = int(r1.y);
+    const int from[kMaxHalv + 1] = {int(r1.z), int(r1.w), int(r2.x), int(r2.y), int(r2.z), int(r2.w)};
+    const int hs[kMaxHalv + 1] = {int(r3.x), int(r3.y), int(r3.z), int(r3.w), int(r4.x), int(r4.y)};
+    const int h1[kMaxHalv + 1] = {int(r4.z), int(r4.w), int(r5.x), int(r5.y), int(r5.z), int(r5.w)};
+    const auto tin = gptr(J.b.tin); const auto tout = gptr(J.b.tout);
+    const uint32_t first = window + uint32_t(lane) * kTpl;
+    const u32x4 w = ((NB_GLOBAL const u32x4 *)tin)[first >> 3];
+    uint32_t pay[kTpl]; int tot[kTpl], one[kTpl], tex[kTpl], oex[kTpl], lt, lo;
+    unpack_window(w, first, start, end, pay, tot, one, tex, oex, lt, lo);
+    const uint32_t incl = wave_scan_incl_dpp((uint32_t(lt) << 16) | uint32_t(lo));
+    const int lane_t = int(incl >> 16) - lt, lane_o = int(incl & 0xFFFF) - lo;
+    uint32_t p[kTpl];
+#pragma unroll
+    for (int k = 0; k < kTpl; k++) {
+        const int j = lane * kTpl + k;
+        int vs = int(r0.w), v1 = int(r1.x);
+#pragma unroll
+        for (int h = 0; h <= kMaxHalv; h++) if (h < n_halv && j >= from[h]) { vs = hs[h]; v1 = h1[h]; }
+        p[k] = prob_one(v1 + lane_o + oex[k], vs + lane_t + tex[k]);
+    }
+    if (first >= start && first + kTpl <= end) {
+        ((NB_GLOBAL u32x4 *)tout)[first >> 3] = u32x4{p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16)};
+    } else {
+#pragma unroll
+        for (int k = 0; k < kTpl; k++) if (first + k >= start && first + k < end) tout[first + k] = uint16_t(p[k]);
+    }
 }
 
 // ---- mix the two trees' probabilities and pack for the host coder (NBLIC.c:629-633) -------
@@ -734,17 +913,20 @@ void e1_launch_front(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipSt
     mark(); hipLaunchKernelGGL(k_adr_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<0>(d_jobs, n_jobs, uint32_t(kContexts) * max_nseg, s, mark);
     mark(); hipLaunchKernelGGL(k_adr_scatter, seg_grid, dim3(256), 0, s, d_jobs);
-    mark(); hipLaunchKernelGGL(k_bias_chains, dim3(kContexts / 64, n_jobs), dim3(64), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_plan_blocks, dim3(1, n_jobs), dim3(1024), 0, s, d_jobs);
+    const unsigned max_blocks = max_n / kBiasBlock + unsigned(kContexts);
+    mark(); hipLaunchKernelGGL(k_bias_blocks, dim3(cdiv(max_blocks, 64), n_jobs), dim3(64), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_bias_fixup, dim3(kContexts / 64, n_jobs), dim3(64), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_map_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<1>(d_jobs, n_jobs, 512u * max_nseg, s, mark);
     mark(); hipLaunchKernelGGL(k_map_scatter, seg_grid, dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_mapper_chains, dim3(512 / 64, n_jobs), dim3(64), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_count_bins, px_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<2>(d_jobs, n_jobs, max_n, s, mark);
-    mark();                                                     // start of the host gap (index 18)
+    mark();                                                     // start of the host gap (index 20)
 }
 
-// Back half: needs n_ev / pe filled in the job records and event-sized buffers.  8 launches.
+// Back half: needs n_ev / pe filled in the job records and event-sized buffers.  10 launches.
 void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm) {
     int max_nseg = 0; uint32_t max_n = 0, max_ev = 0;
     for (int k = 0; k < n_jobs; k++) {
@@ -752,14 +934,17 @@ void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
         max_nseg = h_jobs[k].pe.nseg > max_nseg ? h_jobs[k].pe.nseg : max_nseg;
     }
     const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs);
-    Marker mark{tm, s, 19};
+    Marker mark{tm, s, 21};
     mark(); hipLaunchKernelGGL(k_emit_bins, dim3(cdiv(max_n, 256), n_jobs), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_touch_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<3>(d_jobs, n_jobs, 4096u * max_nseg, s, mark);
     mark(); hipLaunchKernelGGL(k_touch_scatter, seg_grid, dim3(256), 0, s, d_jobs);
-    mark(); hipLaunchKernelGGL(k_counter_chains, dim3(4096, n_jobs), dim3(64), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_plan_windows, dim3(1, n_jobs), dim3(1024), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_counter_epochs, dim3(4096, n_jobs), dim3(64), 0, s, d_jobs);
+    const unsigned max_windows = unsigned(2ull * max_ev / kWin) + 4096u;          // every touch list has <= 2 touches per bin
+    mark(); hipLaunchKernelGGL(k_counter_probs, dim3(cdiv(max_windows, 4), n_jobs), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_mix, dim3(cdiv(max_ev, 256) ? cdiv(max_ev, 256) : 1, n_jobs), dim3(256), 0, s, d_jobs);
-    mark();                                                     // index 27: end
+    mark();                                                     // index 31: end
 }
 
 }  // namespace nblic

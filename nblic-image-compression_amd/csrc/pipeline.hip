@@ -186,6 +186,8 @@ static bool group_init(Group &g, int id, int n_slots, nblic_amd_ctx *c) {
         HIP_OK(hipMalloc((void **)&s.b.ctx_state, kContexts * sizeof(int)));
         HIP_OK(hipMalloc((void **)&s.b.map_state, 512 * 60 * sizeof(int)));
         HIP_OK(hipMalloc((void **)&s.b.cnt_state, 4096 * 2 * sizeof(int)));
+        HIP_OK(hipMalloc((void **)&s.b.win_base, 4097 * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **)&s.b.blk_base, 2049 * sizeof(uint32_t)));
     }
     return true;
 }
@@ -195,7 +197,7 @@ static void group_free(Group &g) {
         hipFree(s.b.rec1); hipFree(s.b.s2in); hipFree(s.b.pos2); hipFree(s.b.s2out); hipFree(s.b.pxs); hipFree(s.b.s3in);
         hipFree(s.b.pos3); hipFree(s.b.s3out); hipFree(s.b.z); hipFree(s.b.cnt); hipFree(s.b.ev_off); hipFree(s.b.table);
         hipFree(s.b.scan_sums); hipFree(s.b.ctx_state); hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events);
-        hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.coded); hipFree(s.d_img);
+        hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.coded); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
         if (s.h_coded) hipHostFree(s.h_coded);
     }
     hipFree(g.d_jobs); hipFree(g.d_totals);
@@ -210,7 +212,8 @@ static bool ensure_events(Slot &s, size_t n_ev) {
     if (n_ev <= s.ev_cap) return true;
     size_t cap = n_ev + n_ev / 8 + 1024;
     if (!dev_alloc(s.b.events, cap) || !dev_alloc(s.b.tin, 2 * cap + kStreamPad) || !dev_alloc(s.b.tpos, cap) ||
-        !dev_alloc(s.b.tout, 2 * cap + kStreamPad) || !dev_alloc(s.b.coded, cap)) return false;
+        !dev_alloc(s.b.tout, 2 * cap + kStreamPad) || !dev_alloc(s.b.coded, cap) ||
+        !dev_alloc(s.b.win_recs, (2 * cap / 512 + 4096 + 8) * 24)) return false;
     if (s.h_coded) hipHostFree(s.h_coded);
     s.h_coded = nullptr;
     HIP_OK(hipHostMalloc((void **)&s.h_coded, cap * sizeof(uint16_t), hipHostMallocDefault));
@@ -224,7 +227,8 @@ static bool ensure_pixels(Slot &s, size_t n) {
         if (!dev_alloc(s.b.rec1, cap) || !dev_alloc(s.b.s2in, cap + kStreamPad) || !dev_alloc(s.b.pos2, cap) ||
             !dev_alloc(s.b.s2out, cap + kStreamPad) || !dev_alloc(s.b.pxs, cap) || !dev_alloc(s.b.s3in, cap + kStreamPad) ||
             !dev_alloc(s.b.pos3, cap) || !dev_alloc(s.b.s3out, cap + kStreamPad) || !dev_alloc(s.b.z, cap) ||
-            !dev_alloc(s.b.cnt, cap) || !dev_alloc(s.b.ev_off, cap)) return false;
+            !dev_alloc(s.b.cnt, cap) || !dev_alloc(s.b.ev_off, cap) || !dev_alloc(s.b.blk_end, cap / 4096 + 2048 + 64) ||
+            !dev_alloc(s.b.blk_ok, cap / 4096 + 2048 + 64)) return false;
         s.px_cap = cap;
     }
     return ensure_events(s, 6 * n);          // typical images need 4.3-4.5 bins/px; grown on demand
@@ -245,6 +249,7 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
         }
         E1Job &J = g.h_jobs[k];
         J.b = s.b; J.h = s.h; J.w = s.w; J.n = uint32_t(n); J.pp = make_plan(J.n); J.n_ev = 0; J.pe = make_plan(0);
+        { static const int dbg = getenv("NBLIC_AMD_DBG") ? atoi(getenv("NBLIC_AMD_DBG")) : 0; J.dbg = dbg; }
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
     e1_launch_front(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);

@@ -77,6 +77,20 @@ def test_mixed_size_batch_equals_oracle(gpu_ctx, oracle):
         assert g == oracle.encode(img, 0, 1)[0], img.shape
 
 
+def test_flat_and_structured_images_multi_block(gpu_ctx, oracle):
+    """Long context chains whose coupled warm-up cannot meet (constant error) must fall back to
+    the in-order replay and still be exact; mixtures exercise both paths inside one chain."""
+    half = inputs.make("const", 200, 300).copy()
+    half[:, 150:] = inputs.make("noise", 200, 150)
+    bands = inputs.make("ramp", 256, 256).copy()
+    bands[64:192] = 200
+    imgs = [inputs.make("const", 200, 300), inputs.make("ramp", 256, 256), inputs.make("checker", 300, 300), half, bands,
+            np.zeros((130, 1000), np.uint8), np.full((500, 90), 255, np.uint8)]
+    got = gpu_ctx.encode_batch(imgs)
+    for k, (img, g) in enumerate(zip(imgs, got)):
+        assert g == oracle.encode(img, 0, 1)[0], k
+
+
 def test_output_capacity_is_enforced(gpu_ctx):
     img = inputs.make("noise", 64, 64)
     outs = [np.empty(600, np.uint8)]                      # noise needs > 4 KB
