@@ -111,8 +111,12 @@ constexpr int kRowWords = 65;
 
 template <class StepFn>
 __device__ __forceinline__ void run_lane_streams(NB_GLOBAL const uint16_t *in, NB_GLOBAL uint16_t *out, uint32_t r,
-                                                 const uint32_t end, const uint32_t out_from, u32x2 *stage, StepFn step) {
+                                                 const uint32_t end, const uint32_t out_from, u32x2 *stage, StepFn step,
+                                                 NB_GLOBAL unsigned long long *dbg = nullptr) {
     const int lane = lane_id();
+    unsigned long long t_stage = 0, t_walk = 0, t_flush = 0, rounds = 0, t0 = 0;
+#define NB_STAMP(acc) do { if (dbg) { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); acc += t1_ - t0; t0 = t1_; } } while (0)
+    if (dbg) t0 = __builtin_amdgcn_s_memtime();
     const auto in_w = (NB_GLOBAL const u32x2 *)in;
     const auto out_w = (NB_GLOBAL u32x2 *)out;
     bool live = r < end;
@@ -135,6 +139,7 @@ __device__ __forceinline__ void run_lane_streams(NB_GLOBAL const uint16_t *in, N
 #pragma unroll
             for (int l = 0; l < 64; l++) regs[l] = in_w[(read_lane(base, l) >> 2) + lane];
         }
+        NB_STAMP(t_stage);
         const int c0 = int(cur_r - cur_base), c1 = int(cur_stop - cur_base);   // ---- walk own row: columns [c0, c1)
         for (int wi = 0; wi < 64; wi++) {
             const bool mine = cur_live && wi * 4 + 3 >= c0 && wi * 4 < c1;
@@ -151,6 +156,7 @@ __device__ __forceinline__ void run_lane_streams(NB_GLOBAL const uint16_t *in, N
             }
         }
         __syncthreads();
+        NB_STAMP(t_walk);
         for (int l = 0; l < 64; l++) {                       // ---- write windows back
             if (((cur_active >> l) & 1ull) == 0ull) continue;
             const uint32_t b = read_lane(cur_base, l), lo = max(read_lane(cur_r, l), read_lane(out_from, l)), hi = read_lane(cur_stop, l);
@@ -166,8 +172,11 @@ __device__ __forceinline__ void run_lane_streams(NB_GLOBAL const uint16_t *in, N
             }
         }
         __syncthreads();
+        NB_STAMP(t_flush); rounds++;
         if (active == 0ull) break;
     }
+    if (dbg && lane == 0) { dbg[0] = t_stage; dbg[1] = t_walk; dbg[2] = t_flush; dbg[3] = rounds; }
+#undef NB_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -415,10 +424,25 @@ __global__ void __launch_bounds__(256) k_map_scatter(const E1Job *__restrict__ j
 }
 
 // ---- S3: re-mapper chains, one lane per (px, sign) (NBLIC.c:470-523) ----------------------
-// Per-lane state (20 ranks, 20 symbols, 20 counts) lives in LDS as [entry][lane] so that the
-// 64 lanes of a wave hit 64 different banks whatever entry each of them indexes.
+// A step is a dependent LDS round trip (~68 cycles) per table it touches, so the two 20-entry
+// permutations (symbol -> rank, rank -> symbol) are kept in REGISTERS, five bits per entry in two
+// 64-bit words each; only the 20 counts stay in LDS, laid out [entry][lane] so that the 64
+// lanes of a wave hit 64 different banks whatever entry each of them indexes.
+struct Perm20 { uint64_t lo, hi; };                                   // entries 0..11 in lo, 12..19 in hi
+__device__ __forceinline__ int perm_get(const Perm20 &p, int i) {
+    const bool up = i >= 12;
+    return int(((up ? p.hi : p.lo) >> (5 * (up ? i - 12 : i))) & 31u);
+}
+__device__ __forceinline__ void perm_set(Perm20 &p, int i, int v) {
+    const bool up = i >= 12;
+    const int sh = 5 * (up ? i - 12 : i);
+    uint64_t w = up ? p.hi : p.lo;
+    w = (w & ~(uint64_t(31) << sh)) | (uint64_t(uint32_t(v)) << sh);
+    if (up) p.hi = w; else p.lo = w;
+}
+
 __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ jobs) {
-    __shared__ int rank_of[kMapSyms][64], sym_at[kMapSyms][64], count[kMapSyms][64];
+    __shared__ int count[kMapSyms][64];
     __shared__ u32x2 stage[64 * kRowWords];
     const E1Job &J = jobs[blockIdx.y];
     const auto s3in = gptr(J.b.s3in); const auto table = gptr(J.b.table);
@@ -427,28 +451,27 @@ __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ 
     const int lane = int(threadIdx.x);
     const int key = int(blockIdx.x) * 64 + lane;
     auto st = map_state + size_t(key) * (3 * kMapSyms);
+    Perm20 rank_of{0, 0}, sym_at{0, 0};
     for (int k = 0; k < kMapSyms; k++) {
-        rank_of[k][lane] = st[k]; sym_at[k][lane] = st[kMapSyms + k]; count[k][lane] = st[2 * kMapSyms + k];
+        perm_set(rank_of, k, st[k]); perm_set(sym_at, k, st[kMapSyms + k]); count[k][lane] = st[2 * kMapSyms + k];
     }
     const uint32_t start = table[size_t(key) * plan.nseg];
     const uint32_t end = key + 1 < 512 ? table[size_t(key + 1) * plan.nseg] : *total;
     run_lane_streams(s3in, s3out, start, end, start, stage, [&](uint32_t y, uint32_t) {
-        int zz = rank_of[y][lane];
-        int c = count[zz][lane] + 1;
+        const int zz = perm_get(rank_of, int(y));
+        const int up = zz > 0 ? zz - 1 : 0;
+        const int c = count[zz][lane] + 1, c_up = count[up][lane];    // both reads in one LDS round trip
         count[zz][lane] = c;
-        if (zz > 0) {
-            int c_up = count[zz - 1][lane];
-            if (c_up < c) {                                       // overtake the rank above
-                int other = sym_at[zz - 1][lane];
-                count[zz][lane] = c_up;  count[zz - 1][lane] = c;
-                sym_at[zz][lane] = other; sym_at[zz - 1][lane] = int(y);
-                rank_of[y][lane] = zz - 1; rank_of[other][lane] = zz;
-            }
+        if (zz > 0 && c_up < c) {                                     // overtake the rank above
+            const int other = perm_get(sym_at, up);
+            count[zz][lane] = c_up;  count[up][lane] = c;
+            perm_set(sym_at, zz, other); perm_set(sym_at, up, int(y));
+            perm_set(rank_of, int(y), up); perm_set(rank_of, other, zz);
         }
         return uint32_t(zz);
-    });
+    }, (J.dbg & 8) ? gptr(J.b.dbg_out) + 64 + blockIdx.x * 4 : nullptr);
     for (int k = 0; k < kMapSyms; k++) {
-        st[k] = rank_of[k][lane]; st[kMapSyms + k] = sym_at[k][lane]; st[2 * kMapSyms + k] = count[k][lane];
+        st[k] = perm_get(rank_of, k); st[kMapSyms + k] = perm_get(sym_at, k); st[2 * kMapSyms + k] = count[k][lane];
     }
 }
 
@@ -583,23 +606,34 @@ constexpr int kMaxHalv = 5;              // halvings that fit in one window (>= 
 struct WinRec {                          // 24 words
     uint32_t first, start, end;          // window's first touch slot (multiple of 8); chain's [start, end)
     int vb_s, vb_1, n_halv;              // virtual base at entry: state before touch j = vb + exclusive prefix(j)
-    int from[kMaxHalv + 1], hs[kMaxHalv + 1], h1[kMaxHalv + 1];
+    struct { int from, vb_s, vb_1; } epoch[kMaxHalv + 1];   // touches >= from use this base instead
 };
 static_assert(sizeof(WinRec) == 96, "WinRec is read as six 16-byte words");
 
-__device__ __forceinline__ void unpack_window(const u32x4 w, uint32_t first, uint32_t start, uint32_t end,
-                                              uint32_t (&pay)[kTpl], int (&tot)[kTpl], int (&one)[kTpl],
-                                              int (&tex)[kTpl], int (&oex)[kTpl], int &lt, int &lo) {
+// Unpacks one lane's eight touches and turns them into window-relative INCLUSIVE prefixes of
+// total weight (tin) and of weight that went to bin 1 (oin); lane_t / lane_o are the exclusive
+// prefixes at the lane's first touch.
+__device__ __forceinline__ void window_prefix(const u32x4 w, uint32_t window, uint32_t start, uint32_t end, int lane,
+                                              uint32_t (&pay)[kTpl], int (&tin)[kTpl], int (&oin)[kTpl], int &lane_t, int &lane_o) {
     const uint32_t p[kTpl] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
-    lt = 0; lo = 0;
+    int tot[kTpl];
+#pragma unroll
+    for (int k = 0; k < kTpl; k++) { pay[k] = p[k]; tot[k] = int(p[k] & 63) + int((p[k] >> 6) & 63); }
+    if (window < start || window + kWin > end) {                       // chain edge (wave-uniform): mask foreign slots
+        const uint32_t first = window + uint32_t(lane) * kTpl;
+#pragma unroll
+        for (int k = 0; k < kTpl; k++) if (first + k < start || first + k >= end) tot[k] = 0;
+    }
+    int lt = 0, lo = 0;
 #pragma unroll
     for (int k = 0; k < kTpl; k++) {
-        const bool ok = first + k >= start && first + k < end;
-        pay[k] = p[k];
-        tot[k] = ok ? int(p[k] & 63) + int((p[k] >> 6) & 63) : 0;
-        one[k] = ((p[k] >> 12) & 1) ? tot[k] : 0;
-        tex[k] = lt; oex[k] = lo; lt += tot[k]; lo += one[k];
+        lt += tot[k]; lo += ((p[k] >> 12) & 1) ? tot[k] : 0;
+        tin[k] = lt; oin[k] = lo;
     }
+    const uint32_t incl = wave_scan_incl_dpp((uint32_t(lt) << 16) | uint32_t(lo));
+    lane_t = int(incl >> 16) - lt; lane_o = int(incl & 0xFFFF) - lo;
+#pragma unroll
+    for (int k = 0; k < kTpl; k++) { tin[k] += lane_t; oin[k] += lane_o; }
 }
 
 // windows per chain -> exclusive scan -> win_base[4097]; one 1024-thread block per job
@@ -628,80 +662,77 @@ __global__ void __launch_bounds__(1024) k_plan_windows(const E1Job *__restrict__
 
 __global__ void __launch_bounds__(64) k_counter_epochs(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
-    const auto tin = gptr(J.b.tin); const auto table = gptr(J.b.table);
+    const auto tin_g = gptr(J.b.tin); const auto table = gptr(J.b.table);
     const auto cnt_state = (NB_GLOBAL i32x2 *)gptr(J.b.cnt_state);
-    const auto recs = (NB_GLOBAL u32x4 *)gptr(J.b.win_recs);
+    const auto recs = gptr(J.b.win_recs);
     const SegPlan plan = J.pe;
     const int key = int(blockIdx.x);
     const int lane = int(threadIdx.x);
     const uint32_t start = table[size_t(key) * plan.nseg];
     const uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * plan.nseg] : gptr(J.b.totals)[3];
     if (start >= end) return;
-    const auto in_w = (NB_GLOBAL const u32x4 *)tin;
+    const auto in_w = (NB_GLOBAL const u32x4 *)tin_g;
     uint32_t rec_i = gptr(J.b.win_base)[key];
     i32x2 st = cnt_state[key];
     int base_s = st.x + st.y, base_1 = st.y;                         // wave-uniform running state
     const int dbg = J.dbg;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const uint32_t first_window = start & ~7u;
     // Three windows in flight: the chain is serial, so its memory latency must be covered by
     // depth.  The loop is unrolled by three over NAMED buffers -- rotating one register set at the
     // back edge makes the compiler wait for the load it has only just issued.
     auto process = [&](const u32x4 w, const uint32_t window) {
-        const uint32_t first = window + uint32_t(lane) * kTpl;
-        uint32_t pay[kTpl]; int tot[kTpl], one[kTpl], tex[kTpl], oex[kTpl], lt, lo;
-        unpack_window(w, first, start, end, pay, tot, one, tex, oex, lt, lo);
-        const uint32_t incl = wave_scan_incl_dpp((uint32_t(lt) << 16) | uint32_t(lo));
-        const int lane_t = int(incl >> 16) - lt, lane_o = int(incl & 0xFFFF) - lo;    // exclusive over lanes
-        const uint32_t last = read_lane(incl, 63);
+        uint32_t pay[kTpl]; int tin[kTpl], oin[kTpl], lane_t, lane_o;
+        window_prefix(w, window, start, end, lane, pay, tin, oin, lane_t, lane_o);
+        const auto rec = recs + size_t(rec_i) * 24;
         int vb_s = base_s, vb_1 = base_1;                           // uniform virtual base of the current epoch
-        int from = 0, n_halv = 0;
-        int r_from[kMaxHalv + 1], r_s[kMaxHalv + 1], r_1[kMaxHalv + 1];
-#pragma unroll
-        for (int h = 0; h <= kMaxHalv; h++) { r_from[h] = 0x7FFFFFFF; r_s[h] = 0; r_1[h] = 0; }
-        const int entry_s = vb_s, entry_1 = vb_1;
+        int n_halv = 0;
+        if (lane == 0) {
+            ((NB_GLOBAL u32x4 *)rec)[0] = u32x4{window, start, end, uint32_t(vb_s)};
+            rec[4] = uint32_t(vb_1);
+        }
 #pragma unroll 1
         for (;;) {
-            // which lane's touches push the sum over the limit first?
-            const uint64_t over = __ballot(lane * kTpl + kTpl - 1 >= from && vb_s + lane_t + lt > kCountLimit);
-            if (over == 0ull || n_halv > kMaxHalv || (dbg & 1)) break;
-            const int H = __ffsll((unsigned long long)over) - 1;
-            // every lane scans its own eight touches; only lane H's answer is read
-            int s_run = vb_s + lane_t, o_run = vb_1 + lane_o, s_at = 0, o_at = 0, k_at = kTpl;
-            uint32_t pay_at = 0;
+            // Prefixes are non-decreasing, so "first touch that lifts the sum over the limit" is a
+            // rank query: lanes wholly below the threshold form a prefix of the wave.
+            const int thr = kCountLimit - vb_s;
+            const int H = __popcll(__ballot(tin[kTpl - 1] <= thr));
+            if (H >= 64) break;
+            int below = 0;
 #pragma unroll
-            for (int k = 0; k < kTpl; k++) {
-                const bool hit = k_at == kTpl && lane * kTpl + k >= from && s_run + tot[k] > kCountLimit;
-                if (hit) { k_at = k; s_at = s_run; o_at = o_run; pay_at = pay[k]; }
-                s_run += tot[k]; o_run += one[k];
+            for (int k = 0; k < kTpl; k++) below += int(tin[k] <= thr);
+            // every lane picks, branch-free, the exclusive prefixes and payload of ITS touch number `below`;
+            // only lane H's pick is read
+            int sel_t = lane_t, sel_o = lane_o; uint32_t sel_p = pay[0];
+#pragma unroll
+            for (int k = 1; k < kTpl; k++) { const bool is = below == k; sel_t = is ? tin[k - 1] : sel_t; sel_o = is ? oin[k - 1] : sel_o; sel_p = is ? pay[k] : sel_p; }
+            const int hk = __builtin_amdgcn_readlane(below, H);
+            const int t_ex = __builtin_amdgcn_readlane(sel_t, H), o_ex = __builtin_amdgcn_readlane(sel_o, H);
+            const uint32_t hp = uint32_t(__builtin_amdgcn_readlane(int(sel_p), H));
+            const int hb = int((hp >> 12) & 1), hw = int(hp & 63) + int((hp >> 6) & 63);
+            // counter_add twice (NBLIC.c:606-618) without branches; the second weight may be 0
+            int c1 = vb_1 + o_ex, c0 = vb_s + t_ex - c1;
+            const int a1 = int(hp & 63), a2 = int((hp >> 6) & 63);
+            c1 += hb ? a1 : 0; c0 += hb ? 0 : a1;
+            int hv = int(c0 + c1 > kCountLimit); c0 = (c0 + hv) >> hv; c1 = (c1 + hv) >> hv;
+            c1 += hb ? a2 : 0; c0 += hb ? 0 : a2;
+            hv = int(c0 + c1 > kCountLimit); c0 = (c0 + hv) >> hv; c1 = (c1 + hv) >> hv;
+            vb_s = c0 + c1 - (t_ex + hw);                           // new base = state after it minus its inclusive prefix
+            vb_1 = c1 - (o_ex + (hb ? hw : 0));
+            if (lane == 0) {
+                const int slot = n_halv < kMaxHalv ? n_halv : kMaxHalv;
+                rec[6 + 3 * slot] = uint32_t(H * kTpl + hk + 1);
+                rec[7 + 3 * slot] = uint32_t(vb_s);
+                rec[8 + 3 * slot] = uint32_t(vb_1);
             }
-            const int hk = int(read_lane(uint32_t(k_at), H));
-            const int hs = int(read_lane(uint32_t(s_at), H)), h1 = int(read_lane(uint32_t(o_at), H));
-            const uint32_t hp = read_lane(pay_at, H);
-            Counter c{hs - h1, h1};
-            const int hb = int((hp >> 12) & 1), hw1 = int(hp & 63), hw2 = int((hp >> 6) & 63);
-            counter_add(c, hb, hw1);
-            if (hw2) counter_add(c, hb, hw2);                       // state after the triggering touch
-            // inclusive prefix of the triggering touch = its pre-state minus the epoch base, plus its own weight
-            const int h_tin = hs - vb_s + hw1 + hw2, h_oin = h1 - vb_1 + (hb ? hw1 + hw2 : 0);
-            vb_s = c.c0 + c.c1 - h_tin; vb_1 = c.c1 - h_oin;
-            from = H * kTpl + hk + 1;
-#pragma unroll
-            for (int h = 0; h <= kMaxHalv; h++) if (h == n_halv) { r_from[h] = from; r_s[h] = vb_s; r_1[h] = vb_1; }
             n_halv++;
         }
-        base_s = vb_s + int(last >> 16); base_1 = vb_1 + int(last & 0xFFFF);
-        if (lane == 0 && !(dbg & 2)) {
-            const auto r = recs + size_t(rec_i) * 6;
-            r[0] = u32x4{window, start, end, uint32_t(entry_s)};
-            r[1] = u32x4{uint32_t(entry_1), uint32_t(n_halv), uint32_t(r_from[0]), uint32_t(r_from[1])};
-            r[2] = u32x4{uint32_t(r_from[2]), uint32_t(r_from[3]), uint32_t(r_from[4]), uint32_t(r_from[5])};
-            r[3] = u32x4{uint32_t(r_s[0]), uint32_t(r_s[1]), uint32_t(r_s[2]), uint32_t(r_s[3])};
-            r[4] = u32x4{uint32_t(r_s[4]), uint32_t(r_s[5]), uint32_t(r_1[0]), uint32_t(r_1[1])};
-            r[5] = u32x4{uint32_t(r_1[2]), uint32_t(r_1[3]), uint32_t(r_1[4]), uint32_t(r_1[5])};
-        }
+        if (lane == 0) rec[5] = uint32_t(n_halv);
+        base_s = vb_s + __builtin_amdgcn_readlane(tin[kTpl - 1], 63);
+        base_1 = vb_1 + __builtin_amdgcn_readlane(oin[kTpl - 1], 63);
         rec_i++;
     };
-    auto fetch = [&](uint32_t window) { return (window < end && !(dbg & 4)) ? in_w[(window >> 3) + lane] : u32x4{0x10101010u, 0x10101010u, 0x10101010u, 0x10101010u}; };
+    auto fetch = [&](uint32_t window) { return window < end ? in_w[(window >> 3) + lane] : u32x4{0u, 0u, 0u, 0u}; };
     u32x4 b0 = fetch(first_window), b1 = fetch(first_window + kWin), b2 = fetch(first_window + 2 * kWin);
     for (uint32_t window = first_window; window < end; window += 3 * kWin) {
         process(b0, window);
@@ -712,6 +743,10 @@ __global__ void __launch_bounds__(64) k_counter_epochs(const E1Job *__restrict__
         b2 = fetch(window + 5 * kWin);
     }
     if (lane == 0) cnt_state[key] = i32x2{base_s - base_1, base_1};
+    if ((dbg & 8) && lane == 0 && end - start > 100000u) {
+        const auto d = gptr(J.b.dbg_out) + 256 + (key & 255) * 4;
+        d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = end - start; d[2] = rec_i - gptr(J.b.win_base)[key]; d[3] = uint32_t(key);
+    }
 }
 
 // one wave per recorded window; grid.x is an upper bound, surplus waves leave at once
@@ -723,17 +758,15 @@ __global__ void __launch_bounds__(256) k_counter_probs(const E1Job *__restrict__
     const auto r = (NB_GLOBAL const u32x4 *)gptr(J.b.win_recs) + size_t(g) * 6;
     const u32x4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
     const uint32_t window = r0.x, start = r0.y, end = r0.z;
-    const int n_halv = int(r1.y);
-    const int from[kMaxHalv + 1] = {int(r1.z), int(r1.w), int(r2.x), int(r2.y), int(r2.z), int(r2.w)};
-    const int hs[kMaxHalv + 1] = {int(r3.x), int(r3.y), int(r3.z), int(r3.w), int(r4.x), int(r4.y)};
-    const int h1[kMaxHalv + 1] = {int(r4.z), int(r4.w), int(r5.x), int(r5.y), int(r5.z), int(r5.w)};
-    const auto tin = gptr(J.b.tin); const auto tout = gptr(J.b.tout);
+    const int n_halv = min(int(r1.y), kMaxHalv + 1);
+    const int from[kMaxHalv + 1] = {int(r1.z), int(r2.y), int(r3.x), int(r3.w), int(r4.z), int(r5.y)};
+    const int hs[kMaxHalv + 1] = {int(r1.w), int(r2.z), int(r3.y), int(r4.x), int(r4.w), int(r5.z)};
+    const int h1[kMaxHalv + 1] = {int(r2.x), int(r2.w), int(r3.z), int(r4.y), int(r5.x), int(r5.w)};
+    const auto tin_g = gptr(J.b.tin); const auto tout = gptr(J.b.tout);
     const uint32_t first = window + uint32_t(lane) * kTpl;
-    const u32x4 w = ((NB_GLOBAL const u32x4 *)tin)[first >> 3];
-    uint32_t pay[kTpl]; int tot[kTpl], one[kTpl], tex[kTpl], oex[kTpl], lt, lo;
-    unpack_window(w, first, start, end, pay, tot, one, tex, oex, lt, lo);
-    const uint32_t incl = wave_scan_incl_dpp((uint32_t(lt) << 16) | uint32_t(lo));
-    const int lane_t = int(incl >> 16) - lt, lane_o = int(incl & 0xFFFF) - lo;
+    const u32x4 w = ((NB_GLOBAL const u32x4 *)tin_g)[first >> 3];
+    uint32_t pay[kTpl]; int tin[kTpl], oin[kTpl], lane_t, lane_o;
+    window_prefix(w, window, start, end, lane, pay, tin, oin, lane_t, lane_o);
     uint32_t p[kTpl];
 #pragma unroll
     for (int k = 0; k < kTpl; k++) {
@@ -741,7 +774,8 @@ __global__ void __launch_bounds__(256) k_counter_probs(const E1Job *__restrict__
         int vs = int(r0.w), v1 = int(r1.x);
 #pragma unroll
         for (int h = 0; h <= kMaxHalv; h++) if (h < n_halv && j >= from[h]) { vs = hs[h]; v1 = h1[h]; }
-        p[k] = prob_one(v1 + lane_o + oex[k], vs + lane_t + tex[k]);
+        const int t_ex = k ? tin[k - 1] : lane_t, o_ex = k ? oin[k - 1] : lane_o;
+        p[k] = prob_one(v1 + o_ex, vs + t_ex);
     }
     if (first >= start && first + kTpl <= end) {
         ((NB_GLOBAL u32x4 *)tout)[first >> 3] = u32x4{p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16)};

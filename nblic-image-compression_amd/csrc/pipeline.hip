@@ -188,6 +188,8 @@ static bool group_init(Group &g, int id, int n_slots, nblic_amd_ctx *c) {
         HIP_OK(hipMalloc((void **)&s.b.cnt_state, 4096 * 2 * sizeof(int)));
         HIP_OK(hipMalloc((void **)&s.b.win_base, 4097 * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.blk_base, 2049 * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **)&s.b.dbg_out, 4096 * sizeof(unsigned long long)));
+        HIP_OK(hipMemset(s.b.dbg_out, 0, 4096 * sizeof(unsigned long long)));
     }
     return true;
 }
@@ -197,7 +199,7 @@ static void group_free(Group &g) {
         hipFree(s.b.rec1); hipFree(s.b.s2in); hipFree(s.b.pos2); hipFree(s.b.s2out); hipFree(s.b.pxs); hipFree(s.b.s3in);
         hipFree(s.b.pos3); hipFree(s.b.s3out); hipFree(s.b.z); hipFree(s.b.cnt); hipFree(s.b.ev_off); hipFree(s.b.table);
         hipFree(s.b.scan_sums); hipFree(s.b.ctx_state); hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events);
-        hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.coded); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
+        hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.coded); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.dbg_out); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
         if (s.h_coded) hipHostFree(s.h_coded);
     }
     hipFree(g.d_jobs); hipFree(g.d_totals);
@@ -499,6 +501,7 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
             case 3: src = s.b.cnt; esz = 1; cnt = n; break;
             case 4: src = s.b.events; esz = 4; cnt = s.n_ev; break;
             case 5: src = s.b.coded; esz = 2; cnt = s.n_ev; break;
+            case 6: src = s.b.dbg_out; esz = 8; cnt = 4096; break;
             default: break;
         }
         if (src && cnt * esz <= out_bytes && hipMemcpy(out, src, cnt * esz, hipMemcpyDeviceToHost) == hipSuccess) count = long(cnt);
