@@ -66,8 +66,11 @@ nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders);
 
 /* Same, with the split of the images in flight spelled out: n_groups groups of group_size
  * images.  A group shares every kernel launch (its serial chains run side by side); while the
- * host codes one group the GPU works on the next.  nblic_amd_create uses two groups.          */
-nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int n_coders);
+ * host codes one group the GPU works on the next.  n_host_buffers (>= n_groups * group_size)
+ * pinned host buffers hold coded-bin streams waiting for a coder thread, so the device
+ * workspace of an image is free again as soon as its stream has been copied out.
+ * nblic_amd_create uses two groups and 2 * n_slots host buffers.                              */
+nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int n_coders, int n_host_buffers);
 void nblic_amd_destroy(nblic_amd_ctx *ctx);
 
 /* Encode n_images gray planes at -n0 -e1 (lossless) into byte-exact .nblic streams.
@@ -118,6 +121,12 @@ size_t nblic_amd_range_code(const uint16_t *coded, size_t n, unsigned char *out,
 /* Synthetic benchmark frame "SYN-1" (SURVEY.md 8d): xorshift32 noise on a triangular ramp with a
  * 16-level texture; deterministic, integer only.  Host function, needs no GPU.              */
 void nblic_amd_syn1(unsigned char *img, int height, int width, uint32_t seed);
+
+/* Same stage for `count` independent streams.  On hosts with AVX-512 eight streams are coded at
+ * once in the eight 64-bit lanes of a vector register (returns 1), otherwise one after the other
+ * (returns 0); the bytes are identical either way.  lens[k] = byte count or (size_t)-1.       */
+int nblic_amd_range_code_multi(const uint16_t *const *coded, const size_t *n, int count, unsigned char *const *outs,
+                               const size_t *caps, size_t *lens);
 
 const char *nblic_amd_version(void);
 

@@ -33,7 +33,7 @@ EXPORTS = (
     "NBLICcompress", "NBLICdecompress", "QNBLICcompress", "QNBLICdecompress", "QNBLICcompressMultiThread",
     "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_set_max_pixels",
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
-    "nblic_amd_range_code", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
+    "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
 )
 
 
@@ -72,7 +72,7 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_create.restype = C.c_void_p
     lib.nblic_amd_create.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.nblic_amd_create_ex.restype = C.c_void_p
-    lib.nblic_amd_create_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.nblic_amd_create_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.nblic_amd_destroy.restype = None
     lib.nblic_amd_destroy.argtypes = [C.c_void_p]
     lib.nblic_amd_encode_batch.restype = C.c_int
@@ -92,6 +92,9 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_debug_stage.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.nblic_amd_range_code.restype = C.c_size_t
     lib.nblic_amd_range_code.argtypes = [C.POINTER(C.c_uint16), C.c_size_t, _u8p, C.c_size_t]
+    lib.nblic_amd_range_code_multi.restype = C.c_int
+    lib.nblic_amd_range_code_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.nblic_amd_selftest.restype = C.c_int
     lib.nblic_amd_selftest.argtypes = [C.c_void_p]
     lib.nblic_amd_syn1.restype = None
@@ -162,16 +165,34 @@ def range_code(coded: np.ndarray, cap: Optional[int] = None) -> Optional[bytes]:
     return out[:n].tobytes()
 
 
+def range_code_multi(streams: Sequence[np.ndarray], caps: Optional[Sequence[int]] = None):
+    """Several bin streams through ``nblic_amd_range_code_multi``.  Returns (list of bytes or None, used_simd)."""
+    lib = load_library()
+    arrs = [np.ascontiguousarray(a, np.uint16) for a in streams]
+    k = len(arrs)
+    caps = [a.size * 4 + 16 for a in arrs] if caps is None else list(caps)
+    outs = [np.empty(max(c, 1), np.uint8) for c in caps]
+    cp = (C.c_void_p * k)(*[C.c_void_p(a.ctypes.data) for a in arrs])
+    nn = (C.c_size_t * k)(*[a.size for a in arrs])
+    op = (C.c_void_p * k)(*[C.c_void_p(o.ctypes.data) for o in outs])
+    cc = (C.c_size_t * k)(*caps)
+    ln = (C.c_size_t * k)()
+    simd = lib.nblic_amd_range_code_multi(cp, nn, k, op, cc, ln)
+    bad = C.c_size_t(-1).value
+    return [None if ln[i] == bad else outs[i][: ln[i]].tobytes() for i in range(k)], simd
+
+
 # ---------------------------------------------------------------------------------------------
 # batch context
 # ---------------------------------------------------------------------------------------------
 class Context:
     """Several images in flight on one GPU (``nblic_amd_create``)."""
 
-    def __init__(self, device: int = 0, n_slots: int = 4, n_coders: int = 4, n_groups: int = 0):
+    def __init__(self, device: int = 0, n_slots: int = 4, n_coders: int = 4, n_groups: int = 0, n_host_buffers: int = 0):
         self.lib = load_library()
         if n_groups > 0:
-            self.handle = self.lib.nblic_amd_create_ex(device, n_groups, (n_slots + n_groups - 1) // n_groups, n_coders)
+            self.handle = self.lib.nblic_amd_create_ex(device, n_groups, (n_slots + n_groups - 1) // n_groups, n_coders,
+                                                       n_host_buffers or 2 * n_slots)
         else:
             self.handle = self.lib.nblic_amd_create(device, n_slots, n_coders)
         if not self.handle:

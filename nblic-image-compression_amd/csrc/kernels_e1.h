@@ -5,10 +5,14 @@
 
 namespace nblic {
 
-constexpr uint32_t kMaxSegments = 1024;   // waves per partition pass
+constexpr uint32_t kMaxSegments = 1024;   // waves per partition pass (pixel partitions)
+// The touch partition keeps 4096 output runs open per wave; with 1024 waves per image that is
+// 4 M partially written lines (512 MB) -- more than the 256 MB Infinity Cache, and rocprof showed
+// 9x write amplification.  256 waves per image keep the open lines of a launch resident.
+constexpr uint32_t kTouchSegments = 256;
 
 struct SegPlan { int nseg; uint32_t seg_len; };
-SegPlan make_plan(uint32_t n_items);
+SegPlan make_plan(uint32_t n_items, uint32_t max_segments = kMaxSegments);
 
 // Device buffers of one image in flight.  Pixel-sized arrays hold n = h*w entries,
 // event-sized arrays hold ev_cap entries.

@@ -922,9 +922,9 @@ static void scan_exclusive(const E1Job *jobs, int n_jobs, uint32_t max_items, hi
     mark(); hipLaunchKernelGGL(k_scan_apply<WHICH>, dim3(nb, n_jobs), dim3(kScanThreads), 0, s, jobs);
 }
 
-SegPlan make_plan(uint32_t n_items) {
+SegPlan make_plan(uint32_t n_items, uint32_t max_segments) {
     SegPlan p;
-    uint32_t want = (n_items + kMaxSegments - 1) / kMaxSegments;          // items per segment
+    uint32_t want = (n_items + max_segments - 1) / max_segments;          // items per segment
     if (want < 1024) want = 1024;
     p.seg_len = (want + 63u) & ~63u;
     p.nseg = int((n_items + p.seg_len - 1) / p.seg_len);

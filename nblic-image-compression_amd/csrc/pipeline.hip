@@ -62,6 +62,9 @@ size_t range_code(const uint16_t *coded, size_t n, uint8_t *out, size_t cap) {
     return size_t(p - out);
 }
 
+bool have_avx512();
+void range_code_x8(const uint16_t *const *coded, const size_t *n, int count, uint8_t *const *outs, const size_t *caps, size_t *lens);
+
 void write_header(uint8_t *p, int h, int w, int near, int k_step, int effort) {   // NBLIC.c:682-694
     memcpy(p, "NBLIC0.3", 8);
     p[8] = 1;
@@ -74,39 +77,13 @@ bool size_ok(int h, int w, long max_px) {                                       
     return h > 0 && w > 0 && h <= NBLIC_MAX_HEIGHT && w <= NBLIC_MAX_WIDTH && long(h) * long(w) <= max_px;
 }
 
-// ---- tiny thread pool ----------------------------------------------------------------------
-class Pool {
-  public:
-    explicit Pool(int n) {
-        for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); });
-    }
-    ~Pool() {
-        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
-    }
-    void submit(std::function<void()> f) {
-        { std::lock_guard<std::mutex> g(m_); q_.push_back(std::move(f)); }
-        cv_.notify_one();
-    }
-  private:
-    void run() {
-        for (;;) {
-            std::function<void()> f;
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [this] { return stop_ || !q_.empty(); });
-                if (q_.empty()) return;
-                f = std::move(q_.front()); q_.pop_front();
-            }
-            f();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::deque<std::function<void()>> q_;
-    std::mutex m_;
-    std::condition_variable cv_;
-    bool stop_ = false;
+// ---- host side of an image between the GPU and the coder threads ---------------------------
+struct HostBuf { uint16_t *p = nullptr; size_t cap = 0; };         // pinned; receives one image's coded bins
+
+struct ReadyImage {                                                  // everything a coder thread needs
+    int hb, job, h, w;
+    uint32_t n_ev;
+    unsigned char *const *outs; const size_t *caps; long *lens;
 };
 
 // ---- one image in flight -------------------------------------------------------------------
@@ -114,7 +91,7 @@ struct Slot {
     E1Buffers b{};
     size_t px_cap = 0, ev_cap = 0, img_cap = 0;
     uint8_t *d_img = nullptr;         // device copy when the caller hands a host image
-    uint16_t *h_coded = nullptr;      // pinned, ev_cap entries: the coded bins for the host coder
+    int hb = -1;                      // pinned host buffer that receives this image's coded bins
     int job = -1, h = 0, w = 0;       // current image
     uint32_t n_ev = 0;
 };
@@ -129,7 +106,6 @@ struct Group {
     E1Job *h_jobs = nullptr, *d_jobs = nullptr;        // pinned host / device job records
     uint32_t *h_totals = nullptr, *d_totals = nullptr; // 4 words per slot
     int n_jobs = 0;
-    int pending = 0;                                   // coder tasks outstanding (guarded by ctx->fm)
     bool tm_pending = false;                           // timer events recorded, not yet read
     ::nblic_amd_ctx *ctx = nullptr;
     // the batch this group currently serves (valid from launch_back until its coders finish)
@@ -151,13 +127,23 @@ struct nblic_amd_ctx {
     int device = 0;
     long max_px = kMaxPixels;
     bool timing = false;
+    bool simd = false;                    // AVX-512 host: eight streams per coder step
     std::vector<Group> groups;
-    Pool *pool = nullptr;
     std::mutex api;                       // one batch at a time per context
-    std::mutex fm;                        // free-group list, fed by coder threads
+    std::mutex fm;                        // free groups / free host buffers / outstanding work
     std::condition_variable fcv;
     std::deque<int> free_groups;
-    int coding = 0;                       // S6 tasks outstanding
+    std::vector<HostBuf> hbufs;
+    std::deque<int> free_hbufs;
+    int coding = 0;                       // images handed to the GPU whose streams are not finished yet
+    // coder threads
+    std::vector<std::thread> coders;
+    std::mutex rm;
+    std::condition_variable rcv;
+    std::deque<ReadyImage> ready;
+    int idle_coders = 0;
+    int batch_to_come = 0;                // images of the running batch that have not reached `ready` yet (guarded by rm)
+    bool stop = false;
     // reporting
     double stage_ms[kE1Kernels] = {0};
     long stage_launches = 0;
@@ -200,7 +186,6 @@ static void group_free(Group &g) {
         hipFree(s.b.pos3); hipFree(s.b.s3out); hipFree(s.b.z); hipFree(s.b.cnt); hipFree(s.b.ev_off); hipFree(s.b.table);
         hipFree(s.b.scan_sums); hipFree(s.b.ctx_state); hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events);
         hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.coded); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.dbg_out); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
-        if (s.h_coded) hipHostFree(s.h_coded);
     }
     hipFree(g.d_jobs); hipFree(g.d_totals);
     if (g.h_jobs) hipHostFree(g.h_jobs);
@@ -216,9 +201,6 @@ static bool ensure_events(Slot &s, size_t n_ev) {
     if (!dev_alloc(s.b.events, cap) || !dev_alloc(s.b.tin, 2 * cap + kStreamPad) || !dev_alloc(s.b.tpos, cap) ||
         !dev_alloc(s.b.tout, 2 * cap + kStreamPad) || !dev_alloc(s.b.coded, cap) ||
         !dev_alloc(s.b.win_recs, (2 * cap / 512 + 4096 + 8) * 24)) return false;
-    if (s.h_coded) hipHostFree(s.h_coded);
-    s.h_coded = nullptr;
-    HIP_OK(hipHostMalloc((void **)&s.h_coded, cap * sizeof(uint16_t), hipHostMallocDefault));
     s.ev_cap = cap;
     return true;
 }
@@ -250,7 +232,7 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
             s.b.img = s.d_img;
         }
         E1Job &J = g.h_jobs[k];
-        J.b = s.b; J.h = s.h; J.w = s.w; J.n = uint32_t(n); J.pp = make_plan(J.n); J.n_ev = 0; J.pe = make_plan(0);
+        J.b = s.b; J.h = s.h; J.w = s.w; J.n = uint32_t(n); J.pp = make_plan(J.n); J.n_ev = 0; J.pe = make_plan(0, kTouchSegments);
         { static const int dbg = getenv("NBLIC_AMD_DBG") ? atoi(getenv("NBLIC_AMD_DBG")) : 0; J.dbg = dbg; }
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
@@ -259,31 +241,71 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
     return true;
 }
 
-// Runs on a HIP runtime thread when the group's device->host copies have landed: hands every
-// image of the group to the coder threads.  (No HIP calls are allowed in here.)
+// Coder thread.  Measured on the GPU box (EPYC 9575F): one stream alone codes 500 Mbins/s, eight
+// streams in the lanes of one AVX-512 register 1060 Mbins/s together -- twice the throughput of
+// the thread, at 3.8x the latency of each stream.  So a thread takes a single image while there
+// are enough idle threads to go round (shortest latency, right for a short batch and for its
+// tail) and a pack of eight only when work is piling up.
+static void coder_main(nblic_amd_ctx *c) {
+    for (;;) {
+        ReadyImage im[8];
+        int take = 0;
+        {
+            std::unique_lock<std::mutex> l(c->rm);
+            c->idle_coders++;
+            c->rcv.wait(l, [c] { return c->stop || !c->ready.empty(); });
+            if (c->ready.empty()) return;
+            // A pack pays only when every other thread is busy and plenty of work is left: eight
+            // streams take 3.8x as long as one, so a short batch (or the tail of a long one) finishes
+            // sooner as singles spread over the threads (policy picked with a discrete-event model).
+            const size_t q = c->ready.size(), left = q + size_t(c->batch_to_come);
+            take = (c->simd && q >= 8 && c->idle_coders == 1 && left >= 3 * c->coders.size()) ? 8 : 1;
+            c->idle_coders--;
+            for (int k = 0; k < take; k++) { im[k] = c->ready.front(); c->ready.pop_front(); }
+        }
+        auto t0 = std::chrono::steady_clock::now();
+        const uint16_t *src[8]; size_t n[8], caps[8], lens[8]; uint8_t *dst[8];
+        double bins = 0;
+        for (int k = 0; k < take; k++) {
+            src[k] = c->hbufs[size_t(im[k].hb)].p; n[k] = im[k].n_ev; bins += double(im[k].n_ev);
+            const size_t cap = im[k].caps[im[k].job];
+            dst[k] = im[k].outs[im[k].job] + kHeaderBytes;
+            caps[k] = cap >= size_t(kHeaderBytes) ? cap - kHeaderBytes : 0;
+            if (cap >= size_t(kHeaderBytes)) write_header(im[k].outs[im[k].job], im[k].h, im[k].w, 0, kMinKStep, 1);
+        }
+        if (take > 1) range_code_x8(src, n, take, dst, caps, lens);
+        else lens[0] = range_code(src[0], n[0], dst[0], caps[0]);
+        for (int k = 0; k < take; k++) {
+            if (lens[k] == SIZE_MAX) fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", im[k].job, im[k].caps[im[k].job]);
+            im[k].lens[im[k].job] = lens[k] == SIZE_MAX ? -1 : long(kHeaderBytes + lens[k]);
+        }
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; }
+        {
+            std::lock_guard<std::mutex> l(c->fm);
+            for (int k = 0; k < take; k++) c->free_hbufs.push_back(im[k].hb);
+            c->coding -= take;
+        }
+        c->fcv.notify_all();
+    }
+}
+
+// Runs on a HIP runtime thread when the group's device->host copies have landed: queues the
+// images for the coder threads and hands the device workspace back.  (No HIP calls in here.)
 static void on_group_copied(void *vp) {
     Group *gp = static_cast<Group *>(vp);
     nblic_amd_ctx *c = gp->ctx;
-    for (int k = 0; k < gp->n_jobs; k++) {
-        Slot *sp = &gp->slots[size_t(k)];
-        c->pool->submit([c, sp, gp] {
-            Slot &s = *sp;
-            auto t0 = std::chrono::steady_clock::now();
-            const int job = s.job;
-            long len = -1;
-            if (gp->caps[job] >= size_t(kHeaderBytes) + 4) {
-                write_header(gp->outs[job], s.h, s.w, 0, kMinKStep, 1);
-                size_t body = range_code(s.h_coded, s.n_ev, gp->outs[job] + kHeaderBytes, gp->caps[job] - kHeaderBytes);
-                if (body != SIZE_MAX) len = long(kHeaderBytes + body);
-                else fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", job, gp->caps[job]);
-            }
-            gp->lens[job] = len;
-            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += double(s.n_ev); c->coder_s += dt; }
-            { std::lock_guard<std::mutex> l(c->fm); if (--gp->pending == 0) c->free_groups.push_back(gp->id); c->coding--; }
-            c->fcv.notify_all();
-        });
+    {
+        std::lock_guard<std::mutex> l(c->rm);
+        for (int k = 0; k < gp->n_jobs; k++) {
+            const Slot &s = gp->slots[size_t(k)];
+            c->ready.push_back(ReadyImage{s.hb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens});
+        }
+        c->batch_to_come -= gp->n_jobs;
     }
+    c->rcv.notify_all();
+    { std::lock_guard<std::mutex> l(c->fm); c->free_groups.push_back(gp->id); }
+    c->fcv.notify_all();
 }
 
 static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders) {
@@ -294,17 +316,30 @@ static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders) {
         if (s.n_ev >= 0x7FFFFFFFu) { fprintf(stderr, "[nblic_amd] event count overflow\n"); return false; }
         if (!ensure_events(s, s.n_ev)) return false;
         E1Job &J = g.h_jobs[k];
-        J.b = s.b; J.n_ev = s.n_ev; J.pe = make_plan(s.n_ev);
+        J.b = s.b; J.n_ev = s.n_ev; J.pe = make_plan(s.n_ev, kTouchSegments);
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
     e1_launch_back(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);
     g.tm_pending = c->timing;
     for (int k = 0; k < g.n_jobs; k++) {
         Slot &s = g.slots[size_t(k)];
-        HIP_OK(hipMemcpyAsync(s.h_coded, s.b.coded, size_t(s.n_ev) * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
+        {   // a pinned host buffer for the coded bins; they outnumber the device slots, so the GPU
+            // can move on to the next images while these wait for a coder thread
+            std::unique_lock<std::mutex> l(c->fm);
+            c->fcv.wait(l, [c] { return !c->free_hbufs.empty(); });
+            s.hb = c->free_hbufs.front(); c->free_hbufs.pop_front();
+        }
+        HostBuf &hb = c->hbufs[size_t(s.hb)];
+        if (hb.cap < size_t(s.n_ev) + 8) {
+            if (hb.p) hipHostFree(hb.p);
+            hb.p = nullptr;
+            hb.cap = size_t(s.n_ev) + size_t(s.n_ev) / 8 + 1024;
+            HIP_OK(hipHostMalloc((void **)&hb.p, hb.cap * sizeof(uint16_t), hipHostMallocDefault));
+        }
+        HIP_OK(hipMemcpyAsync(hb.p, s.b.coded, size_t(s.n_ev) * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
     }
     if (with_coders) {
-        { std::lock_guard<std::mutex> l(c->fm); g.pending = g.n_jobs; c->coding += g.n_jobs; }
+        { std::lock_guard<std::mutex> l(c->fm); c->coding += g.n_jobs; }
         HIP_OK(hipLaunchHostFunc(g.stream, on_group_copied, &g));
     }
     return true;
@@ -336,6 +371,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
     c->total_bins = 0; c->coder_s = 0;
     bool ok = true;
     for (int k = 0; k < n_images; k++) lens[k] = -1;
+    { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come = n_images; }
     int next = 0;
     while (next < n_images) {
         int id;
@@ -350,7 +386,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
         g.n_jobs = 0;
         while (next < n_images && g.n_jobs < int(g.slots.size())) {
             int k = next++;
-            if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; continue; }
+            if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; std::lock_guard<std::mutex> l(c->rm); c->batch_to_come--; continue; }
             Slot &s = g.slots[size_t(g.n_jobs++)];
             s.job = k; s.h = hs[k]; s.w = ws[k];
         }
@@ -358,6 +394,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
         if (!launch_front(c, g, imgs, on_device) || !launch_back(c, g, true)) {
             ok = false;
             hipStreamSynchronize(g.stream);
+            { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come -= g.n_jobs; }
             release_group(c, id);
         }
     }
@@ -394,6 +431,17 @@ size_t nblic_amd_range_code(const uint16_t *coded, size_t n, unsigned char *out,
     return range_code(coded, n, out, cap);
 }
 
+int nblic_amd_range_code_multi(const uint16_t *const *coded, const size_t *n, int count, unsigned char *const *outs,
+                               const size_t *caps, size_t *lens) {
+    if (count < 0) return -1;
+    if (have_avx512()) {
+        for (int k = 0; k < count; k += 8) range_code_x8(coded + k, n + k, count - k < 8 ? count - k : 8, outs + k, caps + k, lens + k);
+        return 1;
+    }
+    for (int k = 0; k < count; k++) lens[k] = range_code(coded[k], n[k], outs[k], caps[k]);
+    return 0;
+}
+
 int nblic_amd_selftest(nblic_amd_ctx *c) {
     if (!c || hipSetDevice(c->device) != hipSuccess) return -1;
     return e1_selftest(c->groups[0].stream);
@@ -413,7 +461,7 @@ void nblic_amd_syn1(unsigned char *img, int h, int w, uint32_t seed) {
 
 const char *nblic_amd_version(void) { return "nblic_amd 0.1 (NBLIC v0.3 bitstream, gfx950)"; }
 
-nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int n_coders) {
+nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int n_coders, int n_host_buffers) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         fprintf(stderr, "[nblic_amd] no HIP device available -- this library has no CPU fallback\n");
@@ -426,15 +474,19 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     if (n_groups < 1) n_groups = 1;
     if (group_size < 1) group_size = 1;
     if (n_coders < 1) n_coders = 1;
+    if (n_host_buffers < n_groups * group_size) n_host_buffers = n_groups * group_size;
     auto *c = new nblic_amd_ctx;
     c->device = device;
+    c->simd = have_avx512() && !getenv("NBLIC_AMD_NO_SIMD");
     c->groups.resize(size_t(n_groups));
     for (int i = 0; i < n_groups; i++) {
         if (!group_init(c->groups[size_t(i)], i, group_size, c)) { nblic_amd_destroy(c); return nullptr; }
         c->free_groups.push_back(i);
     }
+    c->hbufs.resize(size_t(n_host_buffers));
+    for (int i = 0; i < n_host_buffers; i++) c->free_hbufs.push_back(i);
     if (!c->serial.init()) { nblic_amd_destroy(c); return nullptr; }
-    c->pool = new Pool(n_coders);
+    for (int i = 0; i < n_coders; i++) c->coders.emplace_back(coder_main, c);
     return c;
 }
 
@@ -443,14 +495,17 @@ nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders) {
     // works on one while the host codes the other
     if (n_slots < 1) n_slots = 1;
     int n_groups = n_slots >= 2 ? 2 : 1;
-    return nblic_amd_create_ex(device, n_groups, (n_slots + n_groups - 1) / n_groups, n_coders);
+    return nblic_amd_create_ex(device, n_groups, (n_slots + n_groups - 1) / n_groups, n_coders, 2 * n_slots);
 }
 
 void nblic_amd_destroy(nblic_amd_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
-    delete c->pool;
+    { std::lock_guard<std::mutex> l(c->rm); c->stop = true; }
+    c->rcv.notify_all();
+    for (auto &t : c->coders) t.join();
     for (auto &g : c->groups) group_free(g);
+    for (auto &hb : c->hbufs) if (hb.p) hipHostFree(hb.p);
     c->serial.destroy();
     delete c;
 }
@@ -506,6 +561,7 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
         }
         if (src && cnt * esz <= out_bytes && hipMemcpy(out, src, cnt * esz, hipMemcpyDeviceToHost) == hipSuccess) count = long(cnt);
     }
+    if (s.hb >= 0) { std::lock_guard<std::mutex> l(c->fm); c->free_hbufs.push_back(s.hb); s.hb = -1; }
     release_group(c, id);
     return count;
 }

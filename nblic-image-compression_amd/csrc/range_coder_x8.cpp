@@ -1,0 +1,149 @@
+// range_coder_x8.cpp -- the serial range-coder stage (NBLIC.c:527-586) for EIGHT images at once.
+//
+// One bin of one stream is a ~9-cycle dependent chain (subtract, 32x32->64 multiply, shift, add,
+// select) that no core can shorten; what a core can do is run eight independent chains in the
+// eight 64-bit lanes of one AVX-512 register.  Every lane is one image's coder: interval
+// [lo, hi] in the low 32 bits of its lane, its own output pointer, its own bin count.  Byte
+// emission is data dependent per lane, so emitted bytes are collected in a per-lane 64-bit
+// accumulator and flushed eight at a time with a scalar store.
+//
+// Bit-exactness: per lane this is instruction for instruction the scalar coder in pipeline.hip
+// (same floor((hi-lo)*prob/4096), same renormalisation loop, same 4-byte flush).
+#include <immintrin.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nblic {
+
+bool have_avx512() {
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
+           __builtin_cpu_supports("avx512vl");
+}
+
+#define NB_TARGET __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,bmi,bmi2,lzcnt")))
+
+namespace {
+
+// Per lane the interval is kept as (lo, span = hi - lo): the multiply then depends on one value.
+struct Lanes {
+    __m512i lo, span, acc, cnt;
+    uint8_t *outp[8], *oend[8];
+    bool overflow[8];
+};
+
+NB_TARGET inline void flush_full(Lanes &L, __mmask8 kf) {
+    alignas(64) uint64_t a[8];
+    _mm512_store_si512((void *)a, L.acc);
+    unsigned m = kf;
+    while (m) {
+        int k = __builtin_ctz(m);
+        m &= m - 1;
+        if (L.outp[k] + 8 <= L.oend[k]) {
+            uint64_t be = __builtin_bswap64(a[k]);
+            __builtin_memcpy(L.outp[k], &be, 8);
+        } else {
+            L.overflow[k] = true;
+        }
+        L.outp[k] += 8;
+    }
+    L.cnt = _mm512_mask_mov_epi64(L.cnt, kf, _mm512_setzero_si512());
+}
+
+// lanes in k shift one byte out (NBLIC.c:563-572); returns the lanes that must shift again
+NB_TARGET inline __mmask8 renorm_once(Lanes &L, __mmask8 k) {
+    const __m512i m32 = _mm512_set1_epi64(0xFFFFFFFFll), top = _mm512_set1_epi64(0xFF000000ll);
+    const __m512i hi = _mm512_add_epi64(L.lo, L.span);
+    k = _mm512_mask_testn_epi64_mask(k, _mm512_xor_si512(L.lo, hi), top);                // top bytes agree
+    L.acc = _mm512_mask_or_epi64(L.acc, k, _mm512_slli_epi64(L.acc, 8), _mm512_srli_epi64(hi, 24));
+    L.cnt = _mm512_mask_add_epi64(L.cnt, k, L.cnt, _mm512_set1_epi64(1));
+    L.lo = _mm512_mask_and_epi64(L.lo, k, _mm512_slli_epi64(L.lo, 8), m32);
+    L.span = _mm512_mask_or_epi64(L.span, k, _mm512_slli_epi64(L.span, 8), _mm512_set1_epi64(0xFF));   // span < 2^24 here
+    const __mmask8 kf = _mm512_mask_cmpeq_epi64_mask(k, L.cnt, _mm512_set1_epi64(8));
+    if (__builtin_expect(kf != 0, 0)) flush_full(L, kf);
+    return k;
+}
+
+// one bin per active lane; ev holds prob | bin << 15 in the low 16 bits of every lane
+NB_TARGET inline void step(Lanes &L, __m512i ev, __mmask8 kact) {
+    const __m512i prob = _mm512_and_si512(ev, _mm512_set1_epi64(0xFFF));
+    const __m512i t1 = _mm512_add_epi64(_mm512_srli_epi64(_mm512_mul_epu32(L.span, prob), 12), _mm512_set1_epi64(1));
+    const __mmask8 kone = _mm512_test_epi64_mask(ev, _mm512_set1_epi64(0x8000));
+    const __mmask8 k1 = kone & kact, k0 = (__mmask8)(~kone) & kact;
+    // bin 1 keeps [lo, cut]: span = t; bin 0 keeps [cut + 1, hi]: lo += t + 1, span -= t + 1
+    L.lo = _mm512_mask_add_epi64(L.lo, k0, L.lo, t1);
+    L.span = _mm512_mask_sub_epi64(L.span, k0, L.span, t1);
+    L.span = _mm512_mask_sub_epi64(L.span, k1, t1, _mm512_set1_epi64(1));
+    __mmask8 k = renorm_once(L, kact);                       // first byte: executed unconditionally, usually a no-op
+    // a second byte in the same step is rare: test before doing the masked work again
+    const __m512i top = _mm512_set1_epi64(0xFF000000ll);
+    k = _mm512_mask_testn_epi64_mask(k, _mm512_xor_si512(L.lo, _mm512_add_epi64(L.lo, L.span)), top);
+    while (__builtin_expect(k != 0, 0)) {
+        renorm_once(L, k);
+        k = _mm512_mask_testn_epi64_mask(k, _mm512_xor_si512(L.lo, _mm512_add_epi64(L.lo, L.span)), top);
+    }
+}
+
+}  // namespace
+
+// Codes `count` (<= 8) streams.  coded[k][0..n[k]) are u16 bins (prob | bin << 15); outs[k] has
+// caps[k] bytes.  lens[k] = bytes written (coder bytes + 4 flush bytes) or SIZE_MAX if it did not fit.
+NB_TARGET void range_code_x8(const uint16_t *const *coded, const size_t *n, int count, uint8_t *const *outs,
+                             const size_t *caps, size_t *lens) {
+    if (count <= 0) return;
+    Lanes L;
+    alignas(64) uint64_t base[8], nn[8];
+    size_t nmin = SIZE_MAX, nmax = 0;
+    for (int k = 0; k < 8; k++) {
+        const int s = k < count ? k : 0;                     // idle lanes read lane 0's (valid) memory, never update
+        base[k] = (uint64_t)(uintptr_t)coded[s];
+        nn[k] = k < count ? n[k] : 0;
+        L.outp[k] = k < count ? outs[k] : nullptr;
+        L.oend[k] = k < count ? outs[k] + caps[k] : nullptr;
+        L.overflow[k] = false;
+        if (k < count) { if (n[k] < nmin) nmin = n[k]; if (n[k] > nmax) nmax = n[k]; }
+    }
+    L.lo = _mm512_setzero_si512();
+    L.span = _mm512_set1_epi64(0xFFFFFFFFll);
+    L.acc = _mm512_setzero_si512();
+    L.cnt = _mm512_setzero_si512();
+    const __m512i vbase = _mm512_load_si512((const void *)base);
+    const __mmask8 kall = (__mmask8)((1u << count) - 1u);
+    size_t r = 0;
+    // all streams alive: one 8-byte gather per lane brings the next four bins of every stream
+    for (; r + 4 <= nmin; r += 4) {
+        const __m512i addr = _mm512_add_epi64(vbase, _mm512_set1_epi64((long long)(2 * r)));
+        const __m512i g = _mm512_i64gather_epi64(addr, (const void *)0, 1);
+        step(L, g, kall);
+        step(L, _mm512_srli_epi64(g, 16), kall);
+        step(L, _mm512_srli_epi64(g, 32), kall);
+        step(L, _mm512_srli_epi64(g, 48), kall);
+    }
+    // ragged tail: lanes drop out as their stream ends
+    for (; r < nmax; r++) {
+        alignas(64) uint64_t e[8];
+        unsigned act = 0;
+        for (int k = 0; k < count; k++) {
+            const bool a = r < nn[k];
+            e[k] = a ? coded[k][r] : 0;
+            act |= unsigned(a) << k;
+        }
+        for (int k = count; k < 8; k++) e[k] = 0;
+        step(L, _mm512_load_si512((const void *)e), (__mmask8)act);
+    }
+    // leftovers of the byte accumulators, then the 4-byte flush of lo (NBLIC.c:576-586)
+    alignas(64) uint64_t a[8], c[8], lo[8];
+    _mm512_store_si512((void *)a, L.acc);
+    _mm512_store_si512((void *)c, L.cnt);
+    _mm512_store_si512((void *)lo, L.lo);
+    for (int k = 0; k < count; k++) {
+        uint8_t *p = L.outp[k];
+        const int left = (int)c[k];
+        if (L.overflow[k] || p + left + 4 > L.oend[k]) { lens[k] = SIZE_MAX; continue; }
+        for (int i = left - 1; i >= 0; i--) *p++ = (uint8_t)(a[k] >> (8 * i));
+        uint32_t v = (uint32_t)lo[k];
+        for (int i = 0; i < 4; i++) { *p++ = (uint8_t)(v >> 24); v <<= 8; }
+        lens[k] = (size_t)(p - outs[k]);
+    }
+}
+
+}  // namespace nblic

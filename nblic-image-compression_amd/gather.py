@@ -22,34 +22,52 @@ def pack(streams: Sequence[bytes | np.ndarray]):
     return payload, lens
 
 
-def gather_streams(streams: Sequence[bytes | np.ndarray], device: torch.device, group=None, dst: int = 0) -> Optional[List[List[bytes]]]:
-    """Every rank contributes its list of streams; rank ``dst`` receives ``[rank][image] -> bytes``
-    (others get None).  Two collectives: an all_gather of the per-image lengths and one padded
-    gather of the payload."""
+def gather_packed(payload: torch.Tensor, lens: torch.Tensor, group=None, dst: int = 0):
+    """Rooted gather of one packed payload per rank.
+
+    payload : 1-D uint8 tensor (on the communication device) holding this rank's streams back to
+              back; lens : 1-D int64 tensor of their lengths on the same device.
+    Rank ``dst`` gets ``(payloads, lengths)``: per rank a uint8 tensor trimmed to its byte count
+    and its int64 length vector, both still on the device; other ranks get None.  Two
+    collectives in all: one all_gather of the (padded) length vectors, one padded gather of the
+    payload -- each non-root GPU sends straight to the root over its own xGMI link.
+    """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    payload, lens = pack(streams)
-    n_img = torch.tensor([len(lens)], dtype=torch.int64, device=device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, n_img, group=group)
-    max_img = int(max(int(c.item()) for c in counts))
-    lens_t = torch.zeros(max_img, dtype=torch.int64, device=device)
-    lens_t[: len(lens)] = torch.from_numpy(lens).to(device)
-    all_lens = [torch.zeros(max_img, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(all_lens, lens_t, group=group)
-    totals = [int(l.sum().item()) for l in all_lens]
-    slot = max(max(totals), 1)
-    buf = torch.zeros(slot, dtype=torch.uint8, device=device)
-    if payload.size:
-        buf[: payload.size] = torch.from_numpy(payload.copy()).to(device)
-    recv = [torch.zeros(slot, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
+    device = payload.device
+    meta = torch.tensor([lens.numel(), int(payload.numel())], dtype=torch.int64, device=device)
+    metas = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    metas = [m.cpu() for m in metas]
+    max_img = max(int(m[0]) for m in metas)
+    slot = max(max(int(m[1]) for m in metas), 1)
+    lens_pad = torch.zeros(max(max_img, 1), dtype=torch.int64, device=device)
+    lens_pad[: lens.numel()] = lens
+    all_lens = [torch.zeros_like(lens_pad) for _ in range(world)]
+    dist.all_gather(all_lens, lens_pad, group=group)
+    if payload.numel() == slot:
+        buf = payload
+    else:
+        buf = torch.zeros(slot, dtype=torch.uint8, device=device)
+        buf[: payload.numel()] = payload
+    recv = [torch.empty(slot, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
     dist.gather(buf, recv, dst=dst, group=group)
     if rank != dst:
         return None
+    return ([recv[r][: int(metas[r][1])] for r in range(world)], [all_lens[r][: int(metas[r][0])] for r in range(world)])
+
+
+def gather_streams(streams: Sequence[bytes | np.ndarray], device: torch.device, group=None, dst: int = 0) -> Optional[List[List[bytes]]]:
+    """Every rank contributes its list of streams; rank ``dst`` receives ``[rank][image] -> bytes``
+    (others get None).  Convenience wrapper over :func:`gather_packed` that stages through host
+    memory on both ends."""
+    payload, lens = pack(streams)
+    got = gather_packed(torch.from_numpy(payload.copy()).to(device), torch.from_numpy(lens).to(device), group, dst)
+    if got is None:
+        return None
     out: List[List[bytes]] = []
-    for r in range(world):
-        host = recv[r].cpu().numpy()
-        ls = all_lens[r].cpu().numpy()[: int(counts[r].item())]
+    for data, ls in zip(*got):
+        host, ls = data.cpu().numpy(), ls.cpu().numpy()
         offs = np.concatenate([[0], np.cumsum(ls)])
         out.append([host[int(offs[k]): int(offs[k + 1])].tobytes() for k in range(len(ls))])
     return out

@@ -57,3 +57,31 @@ def test_product_does_not_reference_oracle(pkg):
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower().replace("no cpu fallback", ""), os.path.join(dirpath, f)
+
+
+def test_multi_stream_range_coder_matches_oracle(pkg, oracle):
+    """The 8-lane AVX-512 coder (or its scalar stand-in) must give the oracle's bytes for every
+    lane, for ragged lengths, fewer / more than eight streams, and must honour capacities."""
+    rng = np.random.default_rng(5)
+    cases = [("syn1", 64, 64), ("noise", 40, 37), ("const", 1, 1), ("checker", 17, 13), ("syn1", 96, 128), ("ramp", 33, 77),
+             ("noise", 64, 64), ("syn1", 100, 30), ("noise", 9, 200), ("checker", 64, 65), ("syn1", 128, 128)]
+    coded, want = [], []
+    for content, h, w in cases:
+        st = oracle.stages(inputs.make(content, h, w))
+        coded.append(st["prob"].astype(np.uint16) | (st["ev_bin"].astype(np.uint16) << 15))
+        want.append(st["body"])
+    for count in (1, 3, 8, 11):
+        got, _ = pkg.range_code_multi(coded[:count])
+        assert got == want[:count], count
+    # random bin streams (all probabilities, long runs of renormalisation)
+    rnd = [(rng.integers(1, 4096, n).astype(np.uint16) | (rng.integers(0, 2, n).astype(np.uint16) << 15)) for n in (5000, 1, 0, 777, 4096, 33, 2500, 9)]
+    got, _ = pkg.range_code_multi(rnd)
+    assert got == [pkg.range_code(r) for r in rnd]
+    skew = [np.full(3000, 1 | (1 << 15), np.uint16), np.full(3000, 4095, np.uint16), np.full(2000, 1, np.uint16)]
+    got, _ = pkg.range_code_multi(skew)
+    assert got == [pkg.range_code(r) for r in skew]
+    # capacity: exact fit passes, one byte less fails for that lane only
+    caps = [len(b) for b in want[:8]]
+    caps[3] -= 1
+    got, _ = pkg.range_code_multi(coded[:8], caps)
+    assert got[3] is None and [g for i, g in enumerate(got) if i != 3] == [b for i, b in enumerate(want[:8]) if i != 3]
