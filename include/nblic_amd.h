@@ -83,6 +83,13 @@ int nblic_amd_encode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned char
                            const int *heights, const int *widths, unsigned char *const *outs,
                            const size_t *out_caps, long *out_lens);
 
+/* Same for effort 0 (QNBLIC): the per-pixel model runs on the GPU, the entropy stage (histogram
+ * normalisation, histogram code, rANS) on a coder thread.  outs[k] are uint16_t buffers; capacities
+ * and lengths are in 16-bit WORDS, like QNBLICcompress's return value.                         */
+int nblic_amd_qencode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned char *const *imgs, int imgs_on_device,
+                            const int *heights, const int *widths, uint16_t *const *outs, const size_t *out_caps_words,
+                            long *out_len_words);
+
 /* Opt-in: raise the pixel-count limit above NBLIC_MAX_IMG_SIZE for this context (config 5 of
  * BASELINE.json exceeds the reference's own limit).  0 restores the reference limit.       */
 void nblic_amd_set_max_pixels(nblic_amd_ctx *ctx, long max_pixels);

@@ -31,7 +31,7 @@ _lib = None
 # every symbol include/nblic_amd.h declares
 EXPORTS = (
     "NBLICcompress", "NBLICdecompress", "QNBLICcompress", "QNBLICdecompress", "QNBLICcompressMultiThread",
-    "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_set_max_pixels",
+    "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_qencode_batch", "nblic_amd_set_max_pixels",
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
     "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
 )
@@ -78,6 +78,9 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_encode_batch.restype = C.c_int
     lib.nblic_amd_encode_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, ip, ip,
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
+    lib.nblic_amd_qencode_batch.restype = C.c_int
+    lib.nblic_amd_qencode_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, ip, ip,
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
     lib.nblic_amd_set_max_pixels.restype = None
     lib.nblic_amd_set_max_pixels.argtypes = [C.c_void_p, C.c_long]
     lib.nblic_amd_enable_timing.restype = None
@@ -151,6 +154,29 @@ def syn1(h: int, w: int, seed: int = 1) -> np.ndarray:
     img = np.empty((h, w), np.uint8)
     load_library().nblic_amd_syn1(img.ctypes.data_as(_u8p), h, w, seed)
     return img
+
+
+def qcompress(img: np.ndarray) -> Optional[bytes]:
+    """``QNBLICcompress`` (effort 0, lossless): the stream as bytes, or None on -1."""
+    lib = load_library()
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.empty(out_capacity(h, w) // 2, np.uint16)
+    words = lib.QNBLICcompress(out.ctypes.data_as(C.POINTER(C.c_uint16)), img.ctypes.data_as(_u8p), h, w)
+    return None if words < 0 else out[:words].tobytes()
+
+
+def qdecompress(stream: bytes) -> Optional[np.ndarray]:
+    """``QNBLICdecompress``: the image, or None on -1."""
+    lib = load_library()
+    if len(stream) < 8:
+        return None
+    buf = np.frombuffer(bytes(stream) + b"\0" * 8, np.uint8).copy().view(np.uint16)
+    h, w = int(buf[2]), int(buf[3])
+    img = np.zeros((max(h, 1), max(w, 1)), np.uint8)
+    hh, ww = C.c_int(), C.c_int()
+    rc = lib.QNBLICdecompress(buf.ctypes.data_as(C.POINTER(C.c_uint16)), img.ctypes.data_as(_u8p), C.byref(hh), C.byref(ww))
+    return None if rc != 0 else img[: hh.value, : ww.value]
 
 
 def range_code(coded: np.ndarray, cap: Optional[int] = None) -> Optional[bytes]:
@@ -242,6 +268,21 @@ class Context:
         planes = [np.ascontiguousarray(i, np.uint8) for i in imgs]
         outs, lens = self.encode_ptrs([p.ctypes.data for p in planes], [p.shape for p in planes], False)
         return [o[:int(n)].tobytes() for o, n in zip(outs, lens)]
+
+    def qencode_batch(self, imgs: Sequence[np.ndarray]) -> List[bytes]:
+        """Effort-0 (QNBLIC) encode of host planes; returns the streams as bytes (little-endian words)."""
+        planes = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        k = len(planes)
+        outs = [np.empty(out_capacity(*p.shape) // 2, np.uint16) for p in planes]
+        ip_ = (C.c_void_p * k)(*[C.c_void_p(p.ctypes.data) for p in planes])
+        hs = (C.c_int * k)(*[p.shape[0] for p in planes])
+        ws = (C.c_int * k)(*[p.shape[1] for p in planes])
+        op = (C.c_void_p * k)(*[C.c_void_p(o.ctypes.data) for o in outs])
+        caps = (C.c_size_t * k)(*[o.size for o in outs])
+        lens = (C.c_long * k)()
+        if self.lib.nblic_amd_qencode_batch(self.handle, k, ip_, 0, hs, ws, op, caps, lens) != 0:
+            raise RuntimeError(f"nblic_amd_qencode_batch failed (lengths {list(lens)})")
+        return [o[: lens[i]].tobytes() for i, o in enumerate(outs)]
 
     def stage_times(self) -> dict:
         ms = (C.c_double * 64)()

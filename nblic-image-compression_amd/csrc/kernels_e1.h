@@ -44,6 +44,7 @@ struct E1Buffers {
     uint32_t *blk_base;      // 2049          first block of every context chain (+ total)
     int      *blk_end;       // n/4096+2048   context state at the end of each block
     uint8_t  *blk_ok;        // n/4096+2048   1 = the block's warm-up copies met (its output is exact)
+    uint32_t *qhist;         // 12 * 256      QNBLIC symbol histograms per activity level
     unsigned long long *dbg_out;   // 4096 words of in-kernel cycle stamps, written only when E1Job::dbg & 8
     uint32_t *win_base;      // 4097          first window record of every counter chain (+ total)
     uint32_t *win_recs;      // 24 words per 512-touch window: entry state + halving epochs (kernels_e1.hip WinRec)
@@ -85,5 +86,8 @@ int e1_selftest(hipStream_t s);     // 0 = DPP wave scan agrees with the shuffle
 // d_jobs: device copy of h_jobs[0..n_jobs).  The host copy is only read to size the grids.
 void e1_launch_front(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm);
 void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm);
+// QNBLIC (effort 0) model stage for a group: leaves level | symbol << 8 per pixel in `pxs` and the
+// 12 x 256 histograms in `qhist`; the entropy stage (normalise, histogram code, rANS) is host work.
+void q_launch_model(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s);
 
 }  // namespace nblic

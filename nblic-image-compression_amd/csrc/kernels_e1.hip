@@ -214,26 +214,47 @@ __device__ __forceinline__ void lds_fill(uint32_t *slice, uint32_t v) {
     for (int k = lane_id(); k < NKEYS; k += 64) slice[k] = v;
 }
 
-// ---- partition 1: pixels by context address (2048 keys) ----------------------------------
+// ---- the two context models that share the partition + coupled-chain machinery -------------
+// NBLIC -e1 (NBLIC.c:413-428): 2048 contexts, clipped 8-bit error, v' = (127 v + 256 e + 64) >> 7,
+// |v| <= 32576, consumer reads v >> 7.   QNBLIC (QNBLIC.c:176-188): 3072 contexts, unclipped
+// 9-bit error, v' = (127 v + 2048 e + 63) >> 7, |v| <= 522303, consumer reads v >> 10.
+struct NbModel {
+    static constexpr int kKeys = kContexts, kKeyBits = 11, kExtreme = 32576, kOutShift = kCtxScale - 1, kScanSel = 0;
+    static __device__ __forceinline__ uint32_t key(uint32_t rec) { return uint32_t(s1_adr(rec)); }
+    static __device__ __forceinline__ uint16_t err_rec(int x, uint32_t rec) { return uint16_t(clip_err(x, s1_px0(rec)) & 0xFF); }
+    static __device__ __forceinline__ int err_of(uint32_t rec16) { return int(int8_t(rec16)); }
+    static __device__ __forceinline__ int update(int v, int e) { return bias_update(v, e); }
+};
+struct QModel {
+    static constexpr int kKeys = 3072, kKeyBits = 12, kExtreme = 1 << 20, kOutShift = 10, kScanSel = 4;
+    static __device__ __forceinline__ uint32_t key(uint32_t rec) { return (rec >> 8) & 0xFFFu; }
+    static __device__ __forceinline__ uint16_t err_rec(int x, uint32_t rec) { return uint16_t((x - int(rec & 0xFF)) & 0xFFFF); }
+    static __device__ __forceinline__ int err_of(uint32_t rec16) { return int(int16_t(rec16)); }
+    static __device__ __forceinline__ int update(int v, int e) { return (v * 128 - v + e * 2048 + 63) >> 7; }
+};
+
+// ---- partition 1: pixels by context address ------------------------------------------------
+template <class M>
 __global__ void __launch_bounds__(256) k_adr_count(const E1Job *__restrict__ jobs) {
-    __shared__ uint32_t lds[4][kContexts];
+    __shared__ uint32_t lds[4][M::kKeys];
     const E1Job &J = jobs[blockIdx.y];
     const auto rec1 = gptr(J.b.rec1); const auto table = gptr(J.b.table);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *hist = lds[threadIdx.x >> 6];
-    lds_fill<kContexts>(hist, 0);
+    lds_fill<M::kKeys>(hist, 0);
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t t = base + lane_id();
-        if (t < hi) atomicAdd(&hist[s1_adr(rec1[t])], 1u);
+        if (t < hi) atomicAdd(&hist[M::key(rec1[t])], 1u);
     }
-    for (int k = lane_id(); k < kContexts; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
+    for (int k = lane_id(); k < M::kKeys; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
 }
 
+template <class M>
 __global__ void __launch_bounds__(256) k_adr_scatter(const E1Job *__restrict__ jobs) {
-    __shared__ uint32_t lds[4][kContexts];
+    __shared__ uint32_t lds[4][M::kKeys];
     const E1Job &J = jobs[blockIdx.y];
     const auto rec1 = gptr(J.b.rec1); const auto x = gptr(J.b.img);
     const auto table = gptr(J.b.table); const auto s2in = gptr(J.b.s2in); const auto pos2 = gptr(J.b.pos2);
@@ -241,18 +262,18 @@ __global__ void __launch_bounds__(256) k_adr_scatter(const E1Job *__restrict__ j
     int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *off = lds[threadIdx.x >> 6];
-    for (int k = lane_id(); k < kContexts; k += 64) off[k] = table[size_t(k) * plan.nseg + seg];
+    for (int k = lane_id(); k < M::kKeys; k += 64) off[k] = table[size_t(k) * plan.nseg + seg];
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t t = base + lane_id();
         bool valid = t < hi;
         uint32_t r = valid ? rec1[t] : 0u;
-        uint32_t key = uint32_t(s1_adr(r));
-        uint64_t same = match_lanes<11>(key, valid);
+        uint32_t key = M::key(r);
+        uint64_t same = match_lanes<M::kKeyBits>(key, valid);
         if (valid) {
             uint32_t rank = __popcll(same & lanes_below());
             uint32_t pos = off[key] + rank;
-            s2in[pos] = uint16_t(clip_err(int(x[t]), s1_px0(r)) & 0xFF);
+            s2in[pos] = M::err_rec(int(x[t]), r);
             pos2[t] = pos;
             if (rank == 0) off[key] += uint32_t(__popcll(same));
         }
@@ -273,19 +294,20 @@ __global__ void __launch_bounds__(256) k_adr_scatter(const E1Job *__restrict__ j
 // not meet (flat regions: a constant error parks them 127 apart) are replayed afterwards from
 // their predecessor's end state by k_bias_fixup, in order -- still exact, just serial.
 constexpr uint32_t kBiasBlock = 4096, kBiasWarm = 3072;
-constexpr int kBiasExtreme = 32576;
 
-// blocks per chain -> exclusive scan -> blk_base[2049]; one 1024-thread block per job
+// blocks per chain -> exclusive scan -> blk_base[kKeys + 1]; one 1024-thread block per job
+template <class M>
 __global__ void __launch_bounds__(1024) k_plan_blocks(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t part[16];
     const E1Job &J = jobs[blockIdx.y];
     const auto table = gptr(J.b.table); const auto blk_base = gptr(J.b.blk_base);
     const int nseg = J.pp.nseg;
-    uint32_t cnt[2], sum = 0;
-    for (int k = 0; k < 2; k++) {
-        int key = int(threadIdx.x) * 2 + k;
+    constexpr int kPer = M::kKeys / 1024;
+    uint32_t cnt[kPer], sum = 0;
+    for (int k = 0; k < kPer; k++) {
+        int key = int(threadIdx.x) * kPer + k;
         uint32_t start = table[size_t(key) * nseg];
-        uint32_t end = key + 1 < kContexts ? table[size_t(key + 1) * nseg] : J.n;
+        uint32_t end = key + 1 < M::kKeys ? table[size_t(key + 1) * nseg] : J.n;
         cnt[k] = (end - start + kBiasBlock - 1) / kBiasBlock;
         sum += cnt[k];
     }
@@ -294,30 +316,31 @@ __global__ void __launch_bounds__(1024) k_plan_blocks(const E1Job *__restrict__ 
     __syncthreads();
     uint32_t pre = incl - sum;
     for (int wv = 0; wv < int(threadIdx.x >> 6); wv++) pre += part[wv];
-    for (int k = 0; k < 2; k++) { blk_base[threadIdx.x * 2 + k] = pre; pre += cnt[k]; }
-    if (threadIdx.x == 1023) blk_base[kContexts] = pre;
+    for (int k = 0; k < kPer; k++) { blk_base[threadIdx.x * kPer + k] = pre; pre += cnt[k]; }
+    if (threadIdx.x == 1023) blk_base[M::kKeys] = pre;
 }
 
 // one LANE per block of any chain; grid.x is an upper bound on the block count
+template <class M>
 __global__ void __launch_bounds__(64) k_bias_blocks(const E1Job *__restrict__ jobs) {
     __shared__ u32x2 stage[64 * kRowWords];
     const E1Job &J = jobs[blockIdx.y];
     const auto s2in = gptr(J.b.s2in); const auto s2out = gptr(J.b.s2out); const auto table = gptr(J.b.table);
     const auto blk_base = gptr(J.b.blk_base); const auto blk_end = gptr(J.b.blk_end);
-    const uint32_t n_items = blk_base[kContexts];
+    const uint32_t n_items = blk_base[M::kKeys];
     const uint32_t item = blockIdx.x * 64u + threadIdx.x;
     if (blockIdx.x * 64u >= n_items) return;                          // whole wave idle
     const bool have = item < n_items;
     // which chain?  largest key with blk_base[key] <= item
     int key = 0;
     if (have) {
-        int lo = 0, hi = kContexts;                                   // invariant: blk_base[lo] <= item < blk_base[hi]
+        int lo = 0, hi = M::kKeys;                                    // invariant: blk_base[lo] <= item < blk_base[hi]
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (blk_base[mid] <= item) lo = mid; else hi = mid; }
         key = lo;
     }
     const int nseg = J.pp.nseg;
     const uint32_t c_start = table[size_t(key) * nseg];
-    const uint32_t c_end = key + 1 < kContexts ? table[size_t(key + 1) * nseg] : J.n;
+    const uint32_t c_end = key + 1 < M::kKeys ? table[size_t(key + 1) * nseg] : J.n;
     const uint32_t blk = have ? item - blk_base[key] : 0u;
     const uint32_t b_start = c_start + blk * kBiasBlock;
     const uint32_t b_end = have ? min(c_end, b_start + kBiasBlock) : 0u;
@@ -325,20 +348,21 @@ __global__ void __launch_bounds__(64) k_bias_blocks(const E1Job *__restrict__ jo
     // warming up from the chain's own first record starts from its true state: both copies equal
     const bool exact = w_start == c_start;
     const int v0 = gptr(J.b.ctx_state)[key];
-    int va = exact ? v0 : -kBiasExtreme, vb = exact ? v0 : kBiasExtreme;
+    int va = exact ? v0 : -M::kExtreme, vb = exact ? v0 : M::kExtreme;
     bool met = false;
     run_lane_streams(s2in, s2out, have ? w_start : 0u, b_end, b_start, stage, [&](uint32_t rec, uint32_t idx) {
-        const int e = int(int8_t(rec));
+        const int e = M::err_of(rec);
         if (idx == b_start) met = va == vb;                           // did the two copies meet during the warm-up?
-        uint32_t o = uint32_t(va >> (kCtxScale - 1));
-        va = bias_update(va, e);
-        if (idx < b_start) vb = bias_update(vb, e);                   // warm-up: carry the second copy too
+        uint32_t o = uint32_t(va >> M::kOutShift);
+        va = M::update(va, e);
+        if (idx < b_start) vb = M::update(vb, e);                     // warm-up: carry the second copy too
         return o;
     });
     if (have) { blk_end[item] = va; gptr(J.b.blk_ok)[item] = uint8_t(met); }
 }
 
 // one lane per chain: replays, in order, the blocks whose warm-up did not meet; publishes the final state
+template <class M>
 __global__ void __launch_bounds__(64) k_bias_fixup(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
     const auto s2in = gptr(J.b.s2in); const auto s2out = gptr(J.b.s2out); const auto table = gptr(J.b.table);
@@ -346,15 +370,15 @@ __global__ void __launch_bounds__(64) k_bias_fixup(const E1Job *__restrict__ job
     const int key = int(blockIdx.x) * 64 + int(threadIdx.x);
     const int nseg = J.pp.nseg;
     const uint32_t c_start = table[size_t(key) * nseg];
-    const uint32_t c_end = key + 1 < kContexts ? table[size_t(key + 1) * nseg] : J.n;
+    const uint32_t c_end = key + 1 < M::kKeys ? table[size_t(key + 1) * nseg] : J.n;
     const uint32_t first = blk_base[key], count = blk_base[key + 1] - first;
     int v = gptr(J.b.ctx_state)[key];
     for (uint32_t b = 0; b < count; b++) {
         if (blk_ok[first + b]) { v = blk_end[first + b]; continue; }
         const uint32_t lo = c_start + b * kBiasBlock, hi = min(c_end, lo + kBiasBlock);
         for (uint32_t r = lo; r < hi; r++) {
-            s2out[r] = uint16_t(v >> (kCtxScale - 1));
-            v = bias_update(v, int(int8_t(s2in[r])));
+            s2out[r] = uint16_t(v >> M::kOutShift);
+            v = M::update(v, M::err_of(s2in[r]));
         }
         blk_end[first + b] = v;
     }
@@ -804,7 +828,7 @@ __global__ void k_init_state(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
     const auto ctx_state = gptr(J.b.ctx_state); const auto map_state = gptr(J.b.map_state); const auto cnt_state = (NB_GLOBAL i32x2 *)gptr(J.b.cnt_state);
     int g = int(blockIdx.x) * 256 + int(threadIdx.x);
-    if (g < kContexts) ctx_state[g] = 0;
+    if (g < 3072) { ctx_state[g] = 0; gptr(J.b.qhist)[g] = 0; }        // 3072: QNBLIC's context count / 12 x 256 histogram bins
     if (g < 4096) cnt_state[g] = i32x2{kWeightOne, kWeightOne};
     if (g < 512)
         for (int k = 0; k < kMapSyms; k++) {
@@ -822,6 +846,7 @@ template <int WHICH> struct ScanSel;
 template <> struct ScanSel<0> { typedef uint32_t T; static __device__ auto in(const E1Job &J) { return gptr(J.b.table); }  static __device__ auto out(const E1Job &J) { return gptr(J.b.table); }  static __device__ uint32_t n(const E1Job &J) { return uint32_t(kContexts) * J.pp.nseg; } };
 template <> struct ScanSel<1> { typedef uint32_t T; static __device__ auto in(const E1Job &J) { return gptr(J.b.table); }  static __device__ auto out(const E1Job &J) { return gptr(J.b.table); }  static __device__ uint32_t n(const E1Job &J) { return 512u * J.pp.nseg; } };
 template <> struct ScanSel<2> { typedef uint8_t  T; static __device__ auto in(const E1Job &J) { return gptr(J.b.cnt); }    static __device__ auto out(const E1Job &J) { return gptr(J.b.ev_off); } static __device__ uint32_t n(const E1Job &J) { return J.n; } };
+template <> struct ScanSel<4> { typedef uint32_t T; static __device__ auto in(const E1Job &J) { return gptr(J.b.table); }  static __device__ auto out(const E1Job &J) { return gptr(J.b.table); }  static __device__ uint32_t n(const E1Job &J) { return 3072u * J.pp.nseg; } };
 template <> struct ScanSel<3> { typedef uint32_t T; static __device__ auto in(const E1Job &J) { return gptr(J.b.table); }  static __device__ auto out(const E1Job &J) { return gptr(J.b.table); }  static __device__ uint32_t n(const E1Job &J) { return 4096u * J.pe.nseg; } };
 
 template <int WHICH>
@@ -861,7 +886,7 @@ __global__ void __launch_bounds__(1024) k_scan_sums(const E1Job *__restrict__ jo
         if (threadIdx.x == 1023) carry = pre + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) gptr(J.b.totals)[WHICH] = carry;
+    if (threadIdx.x == 0) gptr(J.b.totals)[WHICH & 3] = carry;
 }
 
 template <int WHICH>
@@ -881,6 +906,47 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const E1Job *__rest
     uint32_t pre = gptr(J.b.scan_sums)[blockIdx.x] + incl - s;
     for (int wv = 0; wv < int(threadIdx.x >> 6); wv++) pre += part[wv];
     for (int k = 0; k < kScanPerThread; k++) { if (base + k < n) out[base + k] = pre; pre += v[k]; }
+}
+
+// ------------------------------------------------------------------------------------------
+// QNBLIC (effort 0, QNBLIC.c:562-623): stateless predict -> partition by context -> coupled
+// context chains -> symbols + per-level histograms.  Shares the partition / chain kernels above.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_q_predict(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.z];
+    const int w = J.w;
+    int j = int(blockIdx.x) * 256 + int(threadIdx.x);
+    int i = int(blockIdx.y);
+    if (i >= J.h || j >= w) return;
+    const auto img = gptr(J.b.img);
+    auto pix = [&](int r, int c) { return int(img[size_t(r) * size_t(w) + size_t(c)]); };
+    Taps n = sample_taps_q(pix, w, i, j);
+    int px0 = predict_q(n);
+    int err_prev = 0;
+    if (j > 0) err_prev = pix(i, j - 1) - predict_q(sample_taps_q(pix, w, i, j - 1));
+    int qd = level_q(n, err_prev);
+    gptr(J.b.rec1)[size_t(i) * size_t(w) + size_t(j)] = uint32_t(px0) | (uint32_t(context_address_q(n, qd, px0)) << 8);
+}
+
+__global__ void __launch_bounds__(256) k_q_symbols(const E1Job *__restrict__ jobs) {
+    __shared__ uint32_t hist[12 * 256];
+    const E1Job &J = jobs[blockIdx.y];
+    const auto rec1 = gptr(J.b.rec1); const auto x = gptr(J.b.img); const auto s2out = gptr(J.b.s2out);
+    const auto pos2 = gptr(J.b.pos2); const auto qy = gptr(J.b.pxs);
+    for (int k = int(threadIdx.x); k < 12 * 256; k += 256) hist[k] = 0;
+    __syncthreads();
+    const uint32_t n = J.n;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+        const uint32_t r = rec1[t];
+        const int vs = int(int16_t(s2out[pos2[t]]));                 // context state >> 10 as the chain saw it
+        const int sign = vs & 1, qd = int(r >> 16);
+        const int px = iclip(int(r & 0xFF) + (vs >> 1) + sign, 0, kMaxVal);
+        const int y = residual_to_symbol(int(x[t]), px, sign, 0);    // QNBLIC.c:191-202 == NBLIC's map at near 0
+        qy[t] = uint16_t(qd | (y << 8));
+        atomicAdd(&hist[qd * 256 + y], 1u);
+    }
+    __syncthreads();
+    for (int k = int(threadIdx.x); k < 12 * 256; k += 256) if (hist[k]) atomicAdd(J.b.qhist + k, hist[k]);
 }
 
 // self-test: the DPP scan must equal the shuffle scan on arbitrary data
@@ -944,13 +1010,13 @@ void e1_launch_front(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipSt
     Marker mark{tm, s, 0};
     mark(); hipLaunchKernelGGL(k_init_state, dim3(16, n_jobs), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_predict, dim3(cdiv(max_w, 256), max_h, n_jobs), dim3(256), 0, s, d_jobs);
-    mark(); hipLaunchKernelGGL(k_adr_count, seg_grid, dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_adr_count<NbModel>, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<0>(d_jobs, n_jobs, uint32_t(kContexts) * max_nseg, s, mark);
-    mark(); hipLaunchKernelGGL(k_adr_scatter, seg_grid, dim3(256), 0, s, d_jobs);
-    mark(); hipLaunchKernelGGL(k_plan_blocks, dim3(1, n_jobs), dim3(1024), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_adr_scatter<NbModel>, seg_grid, dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_plan_blocks<NbModel>, dim3(1, n_jobs), dim3(1024), 0, s, d_jobs);
     const unsigned max_blocks = max_n / kBiasBlock + unsigned(kContexts);
-    mark(); hipLaunchKernelGGL(k_bias_blocks, dim3(cdiv(max_blocks, 64), n_jobs), dim3(64), 0, s, d_jobs);
-    mark(); hipLaunchKernelGGL(k_bias_fixup, dim3(kContexts / 64, n_jobs), dim3(64), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_bias_blocks<NbModel>, dim3(cdiv(max_blocks, 64), n_jobs), dim3(64), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_bias_fixup<NbModel>, dim3(kContexts / 64, n_jobs), dim3(64), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_map_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<1>(d_jobs, n_jobs, 512u * max_nseg, s, mark);
     mark(); hipLaunchKernelGGL(k_map_scatter, seg_grid, dim3(256), 0, s, d_jobs);
@@ -979,6 +1045,27 @@ void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
     mark(); hipLaunchKernelGGL(k_counter_probs, dim3(cdiv(max_windows, 4), n_jobs), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_mix, dim3(cdiv(max_ev, 256) ? cdiv(max_ev, 256) : 1, n_jobs), dim3(256), 0, s, d_jobs);
     mark();                                                     // index 31: end
+}
+
+void q_launch_model(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s) {
+    int max_w = 0, max_h = 0, max_nseg = 0; uint32_t max_n = 0;
+    for (int k = 0; k < n_jobs; k++) {
+        max_w = h_jobs[k].w > max_w ? h_jobs[k].w : max_w; max_h = h_jobs[k].h > max_h ? h_jobs[k].h : max_h;
+        max_n = h_jobs[k].n > max_n ? h_jobs[k].n : max_n; max_nseg = h_jobs[k].pp.nseg > max_nseg ? h_jobs[k].pp.nseg : max_nseg;
+    }
+    const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs);
+    Marker mark{nullptr, s, 0};
+    hipLaunchKernelGGL(k_init_state, dim3(16, n_jobs), dim3(256), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_q_predict, dim3(cdiv(max_w, 256), max_h, n_jobs), dim3(256), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_adr_count<QModel>, seg_grid, dim3(256), 0, s, d_jobs);
+    scan_exclusive<4>(d_jobs, n_jobs, 3072u * max_nseg, s, mark);
+    hipLaunchKernelGGL(k_adr_scatter<QModel>, seg_grid, dim3(256), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_plan_blocks<QModel>, dim3(1, n_jobs), dim3(1024), 0, s, d_jobs);
+    const unsigned max_blocks = max_n / kBiasBlock + 3072u;
+    hipLaunchKernelGGL(k_bias_blocks<QModel>, dim3(cdiv(max_blocks, 64), n_jobs), dim3(64), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_bias_fixup<QModel>, dim3(3072 / 64, n_jobs), dim3(64), 0, s, d_jobs);
+    unsigned sym_blocks = cdiv(max_n, 256 * 16);                      // 16 pixels per thread: fewer global histogram merges
+    hipLaunchKernelGGL(k_q_symbols, dim3(sym_blocks ? sym_blocks : 1, n_jobs), dim3(256), 0, s, d_jobs);
 }
 
 }  // namespace nblic

@@ -100,6 +100,66 @@ NB_HD int activity(const Taps &n, int err_prev) {
            iabs(n.b - n.f) + iabs(n.d - n.g) + 2 * iabs(err_prev);
 }
 
+// ---- QNBLIC (effort 0) variants, reference: src/QNBLIC.c ------------------------------------
+// Its neighbourhood is a running window (QNBLIC.c:48-79) that differs from direct sampling on
+// rows 0-1 and at column 1; written here in closed form so that a pixel
+// can be evaluated on its own.  `Pix` is only called for in-image coordinates.  Tap t is unused.
+template <class Pix>
+NB_HD Taps sample_taps_q(Pix pix, int w, int i, int j) {
+    Taps n{};
+    auto cl = [w](int c) { return c < 0 ? 0 : (c >= w ? w - 1 : c); };
+    if (i == 0) {
+        auto x0 = [&](int k) { return k >= 0 ? pix(0, k) : kMid; };
+        n.a = x0(j - 1); n.e = x0(j - 2); n.d = n.a; n.b = n.e; n.c = x0(j - 3); n.q = x0(j - 4);
+        n.r = n.a; n.g = n.e; n.f = n.c; n.h = n.q; n.s = x0(j - 5);
+        return n;
+    }
+    const int u0 = pix(i - 1, 0);
+    n.b = pix(i - 1, cl(j)); n.c = pix(i - 1, cl(j - 1)); n.q = pix(i - 1, cl(j - 2)); n.d = pix(i - 1, cl(j + 1));
+    n.a = j >= 1 ? pix(i, j - 1) : u0;
+    n.e = j >= 2 ? pix(i, j - 2) : u0;               // also row i-1's first pixel at j == 1 (the window hands on a(0))
+    if (i == 1) {
+        n.r = j >= 1 ? pix(0, cl(j + 1)) : u0;
+        n.g = j >= 2 ? pix(0, cl(j)) : u0;
+        n.f = j >= 3 ? pix(0, j - 1) : u0;
+        n.h = j >= 4 ? pix(0, j - 2) : u0;
+        n.s = j >= 5 ? pix(0, j - 3) : u0;
+    } else {
+        n.f = pix(i - 2, cl(j)); n.h = pix(i - 2, cl(j - 1)); n.s = pix(i - 2, cl(j - 2));
+        n.g = pix(i - 2, cl(j + 1)); n.r = pix(i - 2, cl(j + 2));
+    }
+    return n;
+}
+
+// QNBLIC.c:94-149: the same seven directions, blend weight 0..7 from (spread >> 3)
+NB_HD int predict_q(const Taps &n) {
+    const int a = n.a, b = n.b, c = n.c, d = n.d, e = n.e, f = n.f, g = n.g, h = n.h, q = n.q, r = n.r, s = n.s;
+    int lin = iclip(9 * (a + b) + 2 * (d - c) - e - f, 0, 16 * kMaxVal);
+    int cw  = 2 * (iabs(a - e) + iabs(c - q) + iabs(b - c) + iabs(d - b));
+    int cn  = 2 * (iabs(a - c) + iabs(c - h) + iabs(b - f) + iabs(d - g));
+    int cnw = 2 * (iabs(a - q) + iabs(c - s) + iabs(b - h) + iabs(d - f));
+    int cne = 2 * (iabs(a - b) + iabs(c - f) + iabs(b - g) + iabs(d - r));
+    int c1  = iabs(2 * a - e - q) + iabs(2 * c - q - s) + iabs(2 * b - c - h) + iabs(2 * d - b - f);
+    int c2  = iabs(2 * a - q - c) + iabs(2 * c - s - h) + iabs(2 * b - h - f) + iabs(2 * d - f - g);
+    int c3  = iabs(2 * a - c - b) + iabs(2 * c - h - f) + iabs(2 * b - f - g) + iabs(2 * d - g - r);
+    int best = cw, ang = 2 * a;
+    keep_min(cn, 2 * b, best, ang);  keep_min(cnw, 2 * c, best, ang); keep_min(cne, 2 * d, best, ang);
+    keep_min(c1, a + c, best, ang);  keep_min(c2, c + b, best, ang);  keep_min(c3, b + d, best, ang);
+    int v = (cw + cn + cnw + cne + c1 + c2 + c3 - 7 * best) >> 3;
+    int wt = (v >= 5) + (v >= 12) + (v >= 34) + (v >= 78) + (v >= 194) + (v >= 431) + (v >= 601);
+    return (8 * wt * ang + (8 - wt) * lin + 64) >> 7;
+}
+// QNBLIC.c:152-161, :599-601: twelve hard levels; err_prev is the UNCLIPPED x - px0 of the left pixel
+NB_HD int level_q(const Taps &n, int err_prev) {
+    int v = activity(n, err_prev);
+    return (v >= 1) + (v >= 2) + (v >= 4) + (v >= 6) + (v >= 9) + (v >= 15) + (v >= 25) + (v >= 39) + (v >= 63) + (v >= 101) + (v >= 151);
+}
+// QNBLIC.c:164-173: level in the high bits, comparisons MSB first
+NB_HD int context_address_q(const Taps &n, int qd, int px0) {
+    return (qd << 8) | (int(px0 > n.a) << 7) | (int(px0 > n.b) << 6) | (int(px0 > n.c) << 5) | (int(px0 > n.d) << 4) |
+           (int(px0 > n.e) << 3) | (int(px0 > n.f) << 2) | (int(px0 > 2 * n.a - n.e) << 1) | int(px0 > 2 * n.b - n.f);
+}
+
 struct Level { int qu, qv, qw; };
 
 NB_HD int level_centre(int k) {

@@ -65,6 +65,8 @@ size_t range_code(const uint16_t *coded, size_t n, uint8_t *out, size_t cap) {
 bool have_avx512();
 void range_code_x8(const uint16_t *const *coded, const size_t *n, int count, uint8_t *const *outs, const size_t *caps, size_t *lens);
 
+long q_entropy_encode(uint16_t *out, size_t cap_words, int h, int w, const uint16_t *qy, const uint32_t *hist_in);
+
 void write_header(uint8_t *p, int h, int w, int near, int k_step, int effort) {   // NBLIC.c:682-694
     memcpy(p, "NBLIC0.3", 8);
     p[8] = 1;
@@ -83,7 +85,8 @@ struct HostBuf { uint16_t *p = nullptr; size_t cap = 0; };         // pinned; re
 struct ReadyImage {                                                  // everything a coder thread needs
     int hb, job, h, w;
     uint32_t n_ev;
-    unsigned char *const *outs; const size_t *caps; long *lens;
+    unsigned char *const *outs; const size_t *caps; long *lens;      // -e1: byte streams; effort 0: uint16_t streams, caps/lens in words
+    int kind;                                                        // 0 = NBLIC -e1 range coder, 1 = QNBLIC entropy stage
 };
 
 // ---- one image in flight -------------------------------------------------------------------
@@ -110,6 +113,7 @@ struct Group {
     ::nblic_amd_ctx *ctx = nullptr;
     // the batch this group currently serves (valid from launch_back until its coders finish)
     unsigned char *const *outs = nullptr; const size_t *caps = nullptr; long *lens = nullptr;
+    int kind = 0;
 };
 
 template <class T> static bool dev_alloc(T *&p, size_t count) {
@@ -169,11 +173,12 @@ static bool group_init(Group &g, int id, int n_slots, nblic_amd_ctx *c) {
         HIP_OK(hipMalloc((void **)&s.b.table, size_t(4096) * kMaxSegments * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.scan_sums, size_t(1) << 20));
         s.b.totals = g.d_totals + size_t(k) * 4;
-        HIP_OK(hipMalloc((void **)&s.b.ctx_state, kContexts * sizeof(int)));
+        HIP_OK(hipMalloc((void **)&s.b.ctx_state, 4096 * sizeof(int)));           // 2048 (NBLIC) or 3072 (QNBLIC) contexts
+        HIP_OK(hipMalloc((void **)&s.b.qhist, 12 * 256 * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.map_state, 512 * 60 * sizeof(int)));
         HIP_OK(hipMalloc((void **)&s.b.cnt_state, 4096 * 2 * sizeof(int)));
         HIP_OK(hipMalloc((void **)&s.b.win_base, 4097 * sizeof(uint32_t)));
-        HIP_OK(hipMalloc((void **)&s.b.blk_base, 2049 * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **)&s.b.blk_base, 4097 * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.dbg_out, 4096 * sizeof(unsigned long long)));
         HIP_OK(hipMemset(s.b.dbg_out, 0, 4096 * sizeof(unsigned long long)));
     }
@@ -185,7 +190,7 @@ static void group_free(Group &g) {
         hipFree(s.b.rec1); hipFree(s.b.s2in); hipFree(s.b.pos2); hipFree(s.b.s2out); hipFree(s.b.pxs); hipFree(s.b.s3in);
         hipFree(s.b.pos3); hipFree(s.b.s3out); hipFree(s.b.z); hipFree(s.b.cnt); hipFree(s.b.ev_off); hipFree(s.b.table);
         hipFree(s.b.scan_sums); hipFree(s.b.ctx_state); hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events);
-        hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.coded); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.dbg_out); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
+        hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.coded); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.dbg_out); hipFree(s.b.qhist); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
     }
     hipFree(g.d_jobs); hipFree(g.d_totals);
     if (g.h_jobs) hipHostFree(g.h_jobs);
@@ -205,17 +210,17 @@ static bool ensure_events(Slot &s, size_t n_ev) {
     return true;
 }
 
-static bool ensure_pixels(Slot &s, size_t n) {
+static bool ensure_pixels(Slot &s, size_t n, bool with_events = true) {
     if (n > s.px_cap) {
         size_t cap = n;
         if (!dev_alloc(s.b.rec1, cap) || !dev_alloc(s.b.s2in, cap + kStreamPad) || !dev_alloc(s.b.pos2, cap) ||
             !dev_alloc(s.b.s2out, cap + kStreamPad) || !dev_alloc(s.b.pxs, cap) || !dev_alloc(s.b.s3in, cap + kStreamPad) ||
             !dev_alloc(s.b.pos3, cap) || !dev_alloc(s.b.s3out, cap + kStreamPad) || !dev_alloc(s.b.z, cap) ||
-            !dev_alloc(s.b.cnt, cap) || !dev_alloc(s.b.ev_off, cap) || !dev_alloc(s.b.blk_end, cap / 4096 + 2048 + 64) ||
-            !dev_alloc(s.b.blk_ok, cap / 4096 + 2048 + 64)) return false;
+            !dev_alloc(s.b.cnt, cap) || !dev_alloc(s.b.ev_off, cap) || !dev_alloc(s.b.blk_end, cap / 4096 + 4096 + 64) ||
+            !dev_alloc(s.b.blk_ok, cap / 4096 + 4096 + 64)) return false;
         s.px_cap = cap;
     }
-    return ensure_events(s, 6 * n);          // typical images need 4.3-4.5 bins/px; grown on demand
+    return with_events ? ensure_events(s, 6 * n) : true;   // typical images need 4.3-4.5 bins/px; grown on demand
 }
 
 // Front half for the images assigned to group g (slots 0..n_jobs-1 already carry job/h/w).
@@ -261,7 +266,23 @@ static void coder_main(nblic_amd_ctx *c) {
             const size_t q = c->ready.size(), left = q + size_t(c->batch_to_come);
             take = (c->simd && q >= 8 && c->idle_coders == 1 && left >= 3 * c->coders.size()) ? 8 : 1;
             c->idle_coders--;
-            for (int k = 0; k < take; k++) { im[k] = c->ready.front(); c->ready.pop_front(); }
+            if (c->ready.front().kind != 0) take = 1;
+            for (int k = 0; k < take; k++) {
+                if (k > 0 && c->ready.front().kind != 0) { take = k; break; }
+                im[k] = c->ready.front(); c->ready.pop_front();
+            }
+        }
+        if (im[0].kind == 1) {                               // QNBLIC: histogram normalisation + rANS, one image per thread
+            const ReadyImage &q = im[0];
+            const uint16_t *qy = c->hbufs[size_t(q.hb)].p;
+            const uint32_t *hist = reinterpret_cast<const uint32_t *>(qy + ((size_t(q.h) * size_t(q.w) + 1) & ~size_t(1)));
+            auto *out = reinterpret_cast<uint16_t *>(q.outs[q.job]);
+            long words = q_entropy_encode(out, q.caps[q.job], q.h, q.w, qy, hist);
+            if (words < 0) fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu words is too small\n", q.job, q.caps[q.job]);
+            q.lens[q.job] = words;
+            { std::lock_guard<std::mutex> l(c->fm); c->free_hbufs.push_back(q.hb); c->coding -= 1; }
+            c->fcv.notify_all();
+            continue;
         }
         auto t0 = std::chrono::steady_clock::now();
         const uint16_t *src[8]; size_t n[8], caps[8], lens[8]; uint8_t *dst[8];
@@ -299,7 +320,7 @@ static void on_group_copied(void *vp) {
         std::lock_guard<std::mutex> l(c->rm);
         for (int k = 0; k < gp->n_jobs; k++) {
             const Slot &s = gp->slots[size_t(k)];
-            c->ready.push_back(ReadyImage{s.hb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens});
+            c->ready.push_back(ReadyImage{s.hb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens, gp->kind});
         }
         c->batch_to_come -= gp->n_jobs;
     }
@@ -382,7 +403,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
         }
         Group &g = c->groups[size_t(id)];
         collect_timing(c, g);                               // events of its previous use are complete by now
-        g.outs = outs; g.caps = caps; g.lens = lens;
+        g.outs = outs; g.caps = caps; g.lens = lens; g.kind = 0;
         g.n_jobs = 0;
         while (next < n_images && g.n_jobs < int(g.slots.size())) {
             int k = next++;
@@ -404,6 +425,88 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
     }
     for (auto &g : c->groups) collect_timing(c, g);
     for (int k = 0; k < n_images; k++) if (lens[k] < 0) ok = false;
+    return ok;
+}
+
+// ---- QNBLIC (effort 0): model on the GPU, entropy stage on a coder thread ---------------------
+static bool launch_q(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, bool on_device) {
+    for (int k = 0; k < g.n_jobs; k++) {
+        Slot &s = g.slots[size_t(k)];
+        size_t n = size_t(s.h) * size_t(s.w);
+        if (!ensure_pixels(s, n, false)) return false;
+        if (on_device) {
+            s.b.img = imgs[s.job];
+        } else {
+            if (n > s.img_cap) { if (!dev_alloc(s.d_img, n)) return false; s.img_cap = n; }
+            HIP_OK(hipMemcpyAsync(s.d_img, imgs[s.job], n, hipMemcpyHostToDevice, g.stream));
+            s.b.img = s.d_img;
+        }
+        E1Job &J = g.h_jobs[k];
+        J.b = s.b; J.h = s.h; J.w = s.w; J.n = uint32_t(n); J.pp = make_plan(J.n); J.n_ev = 0; J.pe = make_plan(0, kTouchSegments); J.dbg = 0;
+        s.n_ev = 0;
+    }
+    HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
+    q_launch_model(g.d_jobs, g.h_jobs, g.n_jobs, g.stream);
+    g.tm_pending = false;
+    for (int k = 0; k < g.n_jobs; k++) {
+        Slot &s = g.slots[size_t(k)];
+        const size_t n = size_t(s.h) * size_t(s.w), n_pad = (n + 1) & ~size_t(1), need = n_pad + 2 * 12 * 256;
+        {
+            std::unique_lock<std::mutex> l(c->fm);
+            c->fcv.wait(l, [c] { return !c->free_hbufs.empty(); });
+            s.hb = c->free_hbufs.front(); c->free_hbufs.pop_front();
+        }
+        HostBuf &hb = c->hbufs[size_t(s.hb)];
+        if (hb.cap < need) {
+            if (hb.p) hipHostFree(hb.p);
+            hb.p = nullptr; hb.cap = need + 1024;
+            HIP_OK(hipHostMalloc((void **)&hb.p, hb.cap * sizeof(uint16_t), hipHostMallocDefault));
+        }
+        HIP_OK(hipMemcpyAsync(hb.p, s.b.pxs, n * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
+        HIP_OK(hipMemcpyAsync(hb.p + n_pad, s.b.qhist, 12 * 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    }
+    { std::lock_guard<std::mutex> l(c->fm); c->coding += g.n_jobs; }
+    HIP_OK(hipLaunchHostFunc(g.stream, on_group_copied, &g));
+    return true;
+}
+
+static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *imgs, bool on_device, const int *hs,
+                           const int *ws, uint16_t *const *outs, const size_t *caps_words, long *len_words) {
+    if (hipSetDevice(c->device) != hipSuccess) return false;
+    bool ok = true;
+    for (int k = 0; k < n_images; k++) len_words[k] = -1;
+    { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come = n_images; }
+    int next = 0;
+    while (next < n_images) {
+        int id;
+        {
+            std::unique_lock<std::mutex> l(c->fm);
+            c->fcv.wait(l, [c] { return !c->free_groups.empty(); });
+            id = c->free_groups.front(); c->free_groups.pop_front();
+        }
+        Group &g = c->groups[size_t(id)];
+        collect_timing(c, g);
+        g.outs = reinterpret_cast<unsigned char *const *>(outs); g.caps = caps_words; g.lens = len_words; g.kind = 1;
+        g.n_jobs = 0;
+        while (next < n_images && g.n_jobs < int(g.slots.size())) {
+            int k = next++;
+            if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; std::lock_guard<std::mutex> l(c->rm); c->batch_to_come--; continue; }
+            Slot &s = g.slots[size_t(g.n_jobs++)];
+            s.job = k; s.h = hs[k]; s.w = ws[k];
+        }
+        if (g.n_jobs == 0) { release_group(c, id); continue; }
+        if (!launch_q(c, g, imgs, on_device)) {
+            ok = false;
+            hipStreamSynchronize(g.stream);
+            { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come -= g.n_jobs; }
+            release_group(c, id);
+        }
+    }
+    {
+        std::unique_lock<std::mutex> l(c->fm);
+        c->fcv.wait(l, [c] { return c->coding == 0; });
+    }
+    for (int k = 0; k < n_images; k++) if (len_words[k] < 0) ok = false;
     return ok;
 }
 
@@ -605,18 +708,33 @@ int NBLICdecompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int
     return c->serial.decode(p_buf, p_img, *p_height, *p_width, *p_near, k_step, *p_effort, c->device);
 }
 
+int nblic_amd_qencode_batch(nblic_amd_ctx *c, int n_images, const unsigned char *const *imgs, int imgs_on_device,
+                            const int *heights, const int *widths, uint16_t *const *outs, const size_t *out_caps_words,
+                            long *out_len_words) {
+    if (!c || n_images < 0) return -1;
+    std::lock_guard<std::mutex> g(c->api);
+    return encode_q_batch(c, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps_words, out_len_words) ? 0 : -1;
+}
+
 int QNBLICcompress(uint16_t *p_buf, unsigned char *p_img, int height, int width) {
-    (void)p_buf; (void)p_img; (void)height; (void)width;
-    fprintf(stderr, "[nblic_amd] QNBLICcompress: effort-0 path not built yet in this round\n");
-    return -1;
+    if (!size_ok(height, width, kMaxPixels)) return -1;                      // QNBLIC.c:575
+    nblic_amd_ctx *c = default_ctx();
+    if (!c) return -1;
+    const unsigned char *imgs[1] = {p_img};
+    uint16_t *outs[1] = {p_buf};
+    size_t caps[1] = {SIZE_MAX / 4};                                          // the reference ABI carries no capacity
+    long lens[1] = {-1};
+    if (nblic_amd_qencode_batch(c, 1, imgs, 0, &height, &width, outs, caps, lens) != 0) return -1;
+    return int(lens[0]);
 }
 int QNBLICdecompress(uint16_t *p_buf, unsigned char *p_img, int *p_height, int *p_width) {
-    (void)p_buf; (void)p_img; (void)p_height; (void)p_width;
-    fprintf(stderr, "[nblic_amd] QNBLICdecompress: effort-0 path not built yet in this round\n");
-    return -1;
+    nblic_amd_ctx *c = default_ctx();
+    if (!c) return -1;
+    std::lock_guard<std::mutex> g(c->api);
+    return c->serial.qdecode(p_buf, p_img, p_height, p_width, kMaxPixels, c->device);
 }
 int QNBLICcompressMultiThread(uint16_t *p_buf, unsigned char *p_img, int height, int width) {
-    return QNBLICcompress(p_buf, p_img, height, width);                      // QNBLIC.c:874-879 (non-Windows build)
+    return QNBLICcompress(p_buf, p_img, height, width);                      // QNBLIC.c:872-883: same stream either way
 }
 
 }  // extern "C"

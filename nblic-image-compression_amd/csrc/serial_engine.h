@@ -22,6 +22,11 @@ struct SerialEngine {
     long encode(uint8_t *out, uint8_t *img, int h, int w, int near, int k_step, int effort, int device);
     // returns 0 / -1
     int decode(const uint8_t *in, uint8_t *img, int h, int w, int near, int k_step, int effort, int device);
+    // QNBLIC (effort 0) decoder: header + histogram tables are parsed on the host, the pixel loop
+    // (model + rANS) runs on the device.  returns 0 / -1
+    int qdecode(const uint16_t *in, uint8_t *img, int *h, int *w, long max_px, int device);
+    uint8_t *d_qtab = nullptr;     // freq[12][256] u32 | start[12][256] u32 | slot[12][32768] u8
+    int *d_status = nullptr;
 };
 
 }  // namespace nblic

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "model.h"
 #include "serial_engine.h"
 
@@ -239,17 +240,61 @@ __global__ void __launch_bounds__(64) k_serial_codec(SerialArgs a) {
     if (a.decode) run_engine<true>(a, S); else run_engine<false>(a, S);
 }
 
+// ---- QNBLIC decoder (QNBLIC.c:493-555): one lane, context table + frequency tables in LDS ----
+struct QDecArgs {
+    uint8_t *img; const uint16_t *words; size_t n_words; size_t pos;
+    int h, w;
+    const uint32_t *freq, *start; const uint8_t *slot;
+    int *status;
+};
+
+__global__ void __launch_bounds__(64) k_serial_qdecode(QDecArgs a) {
+    __shared__ int ctx[3072];
+    __shared__ uint32_t freq[12 * 256], start[12 * 256];
+    for (int k = int(threadIdx.x); k < 3072; k += 64) { ctx[k] = 0; freq[k] = a.freq[k]; start[k] = a.start[k]; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int w = a.w;
+    uint8_t *img = a.img;
+    auto pix = [&](int r, int c) { return int(img[size_t(r) * size_t(w) + size_t(c)]); };
+    size_t pos = a.pos;
+    bool bad = pos + 2 > a.n_words;
+    uint32_t x = bad ? 0u : ((uint32_t(a.words[pos]) << 16) | a.words[pos + 1]);
+    pos += 2;
+    for (int i = 0; i < a.h && !bad; i++) {
+        int err = 0;
+        for (int j = 0; j < w; j++) {
+            const Taps n = sample_taps_q(pix, w, i, j);
+            const int px0 = predict_q(n), qd = level_q(n, err);
+            const int adr = context_address_q(n, qd, px0);
+            const int v = ctx[adr];
+            const int sign = (v >> 10) & 1;
+            const int px = iclip(px0 + (v >> 11) + sign, 0, kMaxVal);
+            const uint32_t low = x & 32767u;
+            const int y = a.slot[size_t(qd) * 32768 + low];
+            x = (x >> 15) * freq[qd * 256 + y] + low - start[qd * 256 + y];
+            if (x < 65536u) { if (pos >= a.n_words) { bad = true; break; } x = (x << 16) | a.words[pos++]; }
+            const int px_out = symbol_to_pixel(y, px, sign, 0);
+            img[size_t(i) * size_t(w) + size_t(j)] = uint8_t(px_out);
+            err = px_out - px0;
+            ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
+        }
+    }
+    *a.status = bad ? -1 : 0;
+}
+
 // ---- host side -------------------------------------------------------------------------------
 #define SE_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     fprintf(stderr, "[nblic_amd] %s failed: %s\n", #call, hipGetErrorString(e_)); return -1; } } while (0)
 
 bool SerialEngine::init() {
     if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
-    return hipMalloc((void **)&d_len, sizeof(long)) == hipSuccess;
+    return hipMalloc((void **)&d_len, sizeof(long)) == hipSuccess && hipMalloc((void **)&d_status, sizeof(int)) == hipSuccess;
 }
 
 void SerialEngine::destroy() {
-    hipFree(d_img); hipFree(d_stream); hipFree(d_stats); hipFree(d_len);
+    hipFree(d_img); hipFree(d_stream); hipFree(d_stats); hipFree(d_len); hipFree(d_qtab); hipFree(d_status);
+    d_qtab = nullptr; d_status = nullptr;
     if (stream) hipStreamDestroy(stream);
     d_img = d_stream = nullptr; d_stats = nullptr; d_len = nullptr; stream = nullptr;
 }
@@ -311,6 +356,41 @@ int SerialEngine::decode(const uint8_t *in, uint8_t *img, int h, int w, int near
     size_t len = readable_span(in, want);
     long r = run_serial(*this, img, in, len, nullptr, h, w, near, k_step, effort, true, device);
     return r < 0 ? -1 : 0;
+}
+
+long q_decode_tables(const uint16_t *in, size_t n_words, int *h, int *w, uint32_t *freq, uint32_t *start, uint8_t *slot);
+
+int SerialEngine::qdecode(const uint16_t *in, uint8_t *img, int *h, int *w, long max_px, int device) {
+    SE_OK(hipSetDevice(device));
+    if (readable_span((const uint8_t *)in, 8) < 8) return -1;
+    if (in[0] != (uint16_t)('Q' | ('0' << 8)) || in[1] != (uint16_t)('.' | ('2' << 8))) return -1;      // QNBLIC.c:475-486
+    *h = in[2]; *w = in[3];
+    if (*h <= 0 || *w <= 0 || long(*h) * long(*w) > max_px) return -1;
+    const size_t n = size_t(*h) * size_t(*w);
+    const size_t n_words = readable_span((const uint8_t *)in, 2 * n + 16384) / 2;
+    const size_t tab_bytes = 2 * 12 * 256 * sizeof(uint32_t) + size_t(12) * 32768;
+    uint8_t *tabs = (uint8_t *)malloc(tab_bytes);
+    if (!tabs) return -1;
+    uint32_t *freq = (uint32_t *)tabs, *start = freq + 12 * 256;
+    uint8_t *slot = tabs + 2 * 12 * 256 * sizeof(uint32_t);
+    long pos = q_decode_tables(in, n_words, h, w, freq, start, slot);
+    if (pos < 0) { free(tabs); return -1; }
+    const size_t stream_bytes = n_words * 2;
+    if (n > img_cap) { hipFree(d_img); d_img = nullptr; SE_OK(hipMalloc((void **)&d_img, n)); img_cap = n; }
+    if (stream_bytes > stream_cap) { hipFree(d_stream); d_stream = nullptr; SE_OK(hipMalloc((void **)&d_stream, stream_bytes)); stream_cap = stream_bytes; }
+    if (!d_qtab) SE_OK(hipMalloc((void **)&d_qtab, tab_bytes));
+    SE_OK(hipMemcpyAsync(d_qtab, tabs, tab_bytes, hipMemcpyHostToDevice, stream));
+    SE_OK(hipMemcpyAsync(d_stream, in, stream_bytes, hipMemcpyHostToDevice, stream));
+    QDecArgs a{d_img, (const uint16_t *)d_stream, n_words, size_t(pos), *h, *w, (const uint32_t *)d_qtab,
+               (const uint32_t *)d_qtab + 12 * 256, d_qtab + 2 * 12 * 256 * sizeof(uint32_t), d_status};
+    hipLaunchKernelGGL(k_serial_qdecode, dim3(1), dim3(64), 0, stream, a);
+    int status = -1;
+    SE_OK(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
+    SE_OK(hipStreamSynchronize(stream));
+    free(tabs);
+    if (status != 0) return -1;
+    SE_OK(hipMemcpy(img, d_img, n, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 }  // namespace nblic

@@ -155,3 +155,43 @@ def test_dropin_decompress_reference_streams(pkg, golden, oracle, near, effort):
 def test_dropin_rejects_bad_input(pkg):
     assert pkg.decompress(b"Q0.2" + bytes(60)) is None                  # not an NBLIC stream
     assert pkg.compress(np.zeros((1, 1), np.uint8), 0, 1)[0] is not None
+
+
+# ---- QNBLIC (effort 0): BASELINE config 1 on the GPU path -------------------------------------
+def test_q_batch_streams_equal_golden(gpu_ctx, golden):
+    _, streams = golden
+    imgs, want = [], []
+    for (h, w) in inputs.SMALL_SHAPES:
+        for content in inputs.CONTENTS:
+            imgs.append(inputs.make(content, h, w))
+            want.append(streams[f"q_{content}_{h}x{w}"].tobytes())
+    got = gpu_ctx.qencode_batch(imgs)
+    for k, (g, wnt) in enumerate(zip(got, want)):
+        assert g == wnt, k
+
+
+def test_q_config1_512_and_4096_hashes(gpu_ctx, golden, oracle):
+    """BASELINE config 1 (512x512 SYN-1, effort 0): golden 50fdb1a0...; and the 4096^2 frame."""
+    from oracle.oracle import syn1
+    manifest, _ = golden
+    for key, hw in (("syn1s1_512x512_q0", 512), ("syn1s1_4096x4096_q0", 4096)):
+        img = syn1(hw, hw, 1)
+        s = gpu_ctx.qencode_batch([img])[0]
+        assert len(s) == manifest["large"][key]["len"] and sha(s) == manifest["large"][key]["sha256"], key
+    assert manifest["large"]["syn1s1_512x512_q0"]["sha256"].startswith("50fdb1a0a3cac171")
+    small = syn1(300, 200, 3)
+    s = gpu_ctx.qencode_batch([small, inputs.make("noise", 100, 333), inputs.make("const", 150, 150)])
+    assert s[0] == oracle.qencode(small) and s[1] == oracle.qencode(inputs.make("noise", 100, 333))
+    assert s[2] == oracle.qencode(inputs.make("const", 150, 150))
+
+
+def test_q_dropin_round_trip(pkg, golden, oracle):
+    _, streams = golden
+    for (h, w) in [(1, 1), (1, 7), (7, 1), (3, 5), (17, 13), (64, 64), (2, 256)]:
+        for content in ("syn1", "noise", "checker"):
+            img = inputs.make(content, h, w)
+            want = streams[f"q_{content}_{h}x{w}"].tobytes()
+            assert pkg.qcompress(img) == want, (content, h, w)
+            dec = pkg.qdecompress(want)                               # a stream the REFERENCE produced
+            assert dec is not None and np.array_equal(dec, img), (content, h, w)
+    assert pkg.qdecompress(b"NBLIC0.3" + bytes(40)) is None
