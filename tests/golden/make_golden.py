@@ -53,6 +53,14 @@ def main():
     for (h, w) in [(512, 512), (4096, 4096)]:
         q = ref.qencode(syn1(h, w, 1))
         manifest["large"][f"syn1s1_{h}x{w}_q0"] = {"len": len(q), "sha256": sha(q)}
+    # Kodak (BASELINE config 3): lengths + hashes only, from images read in place (never copied)
+    if os.path.isdir(inputs.KODAK_DIR):
+        for name in sorted(os.listdir(inputs.KODAK_DIR)):
+            img = inputs.read_gray_bmp(os.path.join(inputs.KODAK_DIR, name))
+            s, _, _, _ = ref.encode(img, 0, 1)
+            q = ref.qencode(img)
+            manifest["kodak_e1"][name] = {"shape": list(img.shape), "input_sha256": sha(img.tobytes()), "len": len(s), "sha256": sha(s),
+                                          "q_len": len(q), "q_sha256": sha(q)}
     np.savez_compressed(os.path.join(HERE, "small_streams.npz"), **streams)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

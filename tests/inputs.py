@@ -56,3 +56,20 @@ def make(content, h, w):
 
 def case_id(content, h, w, near, effort):
     return f"{content}_{h}x{w}_n{near}_e{effort}"
+
+
+KODAK_DIR = "/root/reference/img_kodak"      # read in place, container only; never copied into the repo
+
+
+def read_gray_bmp(path):
+    """8-bit palettised gray BMP as the reference's reader sees it (FileIO.c:170-287): bottom-up
+    rows, 4-byte row padding, pixel = palette index (the Kodak files carry an identity palette)."""
+    import struct
+    raw = open(path, "rb").read()
+    off = struct.unpack_from("<I", raw, 10)[0]
+    w, h = struct.unpack_from("<ii", raw, 18)
+    bpp = struct.unpack_from("<H", raw, 28)[0]
+    assert bpp == 8 and raw[:2] == b"BM"
+    stride = (w + 3) & ~3
+    rows = np.frombuffer(raw, np.uint8, count=stride * abs(h), offset=off).reshape(abs(h), stride)[:, :w]
+    return np.ascontiguousarray(rows[::-1] if h > 0 else rows)

@@ -195,3 +195,20 @@ def test_q_dropin_round_trip(pkg, golden, oracle):
             dec = pkg.qdecompress(want)                               # a stream the REFERENCE produced
             assert dec is not None and np.array_equal(dec, img), (content, h, w)
     assert pkg.qdecompress(b"NBLIC0.3" + bytes(40)) is None
+
+
+def test_config3_kodak_shaped_batch(gpu_ctx, oracle):
+    """BASELINE config 3: 24 images of Kodak's shapes (18 of 512x768 rows x cols... 768x512 and 6
+    portrait), batched.  The Kodak files themselves never leave the build container, so the GPU
+    box runs SYN-1 frames of the same shapes (seeds 1..24) against the oracle; parity of the
+    oracle on the real Kodak pixels is pinned on the CPU side (test_oracle.py)."""
+    from oracle.oracle import syn1
+    shapes = [(512, 768)] * 18 + [(768, 512)] * 6
+    imgs = [syn1(h, w, seed) for seed, (h, w) in enumerate(shapes, start=1)]
+    got = gpu_ctx.encode_batch(imgs)
+    gotq = gpu_ctx.qencode_batch(imgs[:6] + imgs[-3:])
+    for k in (0, 5, 11, 17, 18, 23):
+        assert got[k] == oracle.encode(imgs[k], 0, 1)[0], k
+    assert len(set(got)) == 24
+    for g, im in zip(gotq, imgs[:6] + imgs[-3:]):
+        assert g == oracle.qencode(im)

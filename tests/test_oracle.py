@@ -115,3 +115,26 @@ def test_oracle_vs_live_reference(oracle, reference):
         assert a[0] == b[0] and np.array_equal(a[1], b[1]), (h, w, near, effort)
         d = reference.decode(a[0])
         assert d is not None and np.array_equal(d[0], a[1])
+
+
+def test_oracle_on_kodak_matches_reference_and_readme(oracle, golden):
+    """BASELINE config 3 content.  The 24 Kodak BMPs are third-party files and are read in place
+    (container only); the manifest holds the compiled reference's length + SHA-256 per image, whose
+    totals reproduce the reference README's 4.146 bpp (-e1) and 4.227 bpp (-e0)."""
+    import os
+    manifest, _ = golden
+    k = manifest["kodak_e1"]
+    assert len(k) == 24
+    total_e1 = sum(v["len"] for v in k.values()); total_e0 = sum(v["q_len"] for v in k.values())
+    px = sum(v["shape"][0] * v["shape"][1] for v in k.values())
+    assert (total_e1, total_e0, px) == (4891174, 4985986, 9437184)          # SURVEY appendix A
+    assert round(8 * total_e1 / px, 3) == 4.146 and round(8 * total_e0 / px, 3) == 4.227   # README.md:256-257
+    if not os.path.isdir(inputs.KODAK_DIR):
+        pytest.skip("Kodak images are only present in the build container")
+    for name in ("01.bmp", "13.bmp", "20.bmp"):
+        img = inputs.read_gray_bmp(os.path.join(inputs.KODAK_DIR, name))
+        assert sha(img.tobytes()) == k[name]["input_sha256"]
+        s = oracle.encode(img, 0, 1)[0]
+        assert (len(s), sha(s)) == (k[name]["len"], k[name]["sha256"]), name
+        q = oracle.qencode(img)
+        assert (len(q), sha(q)) == (k[name]["q_len"], k[name]["q_sha256"]), name
