@@ -44,6 +44,29 @@ def cpu_baseline(frames, reps_budget_s=12.0):
             "sample": f"{used} of the batch's {frames[0].shape[0]}x{frames[0].shape[1]} SYN-1 frames, -n0 -e1, one thread"}
 
 
+def profiled_traffic(kernel, images_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, FETCH doubled as the gfx950 guide prescribes;
+    profiles/*_hbm_traffic.csv, produced by tools/summarize_profile.py), rescaled to this run's
+    images per launch.  None when no summary has been committed for that kernel."""
+    import csv, glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
+    if not files:
+        return None
+    meta = {}
+    try:
+        with open(files[-1].replace("_hbm_traffic.csv", "_pmc_config.json")) as f:
+            meta = json.load(f)
+    except OSError:
+        pass
+    prof_ipl = float(meta.get("images_per_launch", 8))
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"].split("(")[0].split("::")[-1] == kernel:
+            return {"GB_per_launch": round(float(row["hbm_MB_per_launch_corrected(2*fetch+write)"]) / 1024 * images_per_launch / prof_ipl, 3),
+                    "source": os.path.basename(files[-1])}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,11 +76,12 @@ def main():
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--coders", type=int, default=0, help="host range-coder threads per GPU (0 = CPU share)")
-    ap.add_argument("--slots", type=int, default=0, help="images in flight per GPU (0 = min(batch, 32))")
-    ap.add_argument("--groups", type=int, default=4, help="launch groups the images in flight are split into")
+    ap.add_argument("--slots", type=int, default=0, help="images in flight per GPU (0 = min(batch, 48))")
+    ap.add_argument("--groups", type=int, default=6, help="launch groups the images in flight are split into")
     ap.add_argument("--host-buffers", type=int, default=0, help="pinned host buffers for coded bins (0 = max(2*slots, batch))")
     ap.add_argument("--host-inputs", action="store_true", help="hand host buffers over (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 path be rehearsed with every rank on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,11 +91,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    gpu = int(os.environ.get("NBLIC_BENCH_DEVICE", local_rank))       # rehearsal: all ranks on one GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+        else:
+            dist.init_process_group(args.dist_backend)
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    comm_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     pkg = importlib.import_module("nblic-image-compression_amd")
     H, W, B = args.height, args.width, args.batch
@@ -81,15 +110,15 @@ def main():
         cpus = os.cpu_count() or 1
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     coders = args.coders or max(1, min(B, 16, cpus // max(1, local_world)))   # 16 = one GPU's CPU share
-    slots = args.slots or min(B, 32)
+    slots = args.slots or min(B, 48)
 
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, min(16, cpus // max(1, local_world)))) as ex:   # the C generator releases the GIL
         frames = list(ex.map(lambda k: pkg.syn1(H, W, seed=rank * B + k + 1), range(B)))
     dev_frames = [torch.from_numpy(f).to(dev) for f in frames]
     torch.cuda.synchronize()
-    host_buffers = args.host_buffers or max(2 * slots, min(B, 128))
-    ctx = pkg.Context(device=local_rank, n_slots=slots, n_coders=coders, n_groups=max(1, min(args.groups, slots)),
+    host_buffers = args.host_buffers or max(slots + 16, min(B, 96))
+    ctx = pkg.Context(device=gpu, n_slots=slots, n_coders=coders, n_groups=max(1, min(args.groups, slots)),
                       n_host_buffers=host_buffers)
     ctx.enable_timing(True)
     # streams land in one pinned slab (a slot per frame: worst case seen is 1.0025 B/px) so that the
@@ -98,7 +127,7 @@ def main():
     slab = torch.empty((B, cap), dtype=torch.uint8, pin_memory=True)
     outs = [slab[k].numpy() for k in range(B)]
     shapes = [(H, W)] * B
-    dev_pack = torch.empty(B * cap, dtype=torch.uint8, device=dev) if world > 1 else None
+    dev_pack = torch.empty(B * cap, dtype=torch.uint8, device=comm_dev) if world > 1 else None
     ptrs = [f.ctypes.data for f in frames] if args.host_inputs else [d.data_ptr() for d in dev_frames]
     gather = None
     if world > 1:
@@ -115,7 +144,7 @@ def main():
                 n = int(lens[k])
                 dev_pack[off:off + n].copy_(slab[k, :n], non_blocking=True)
                 off += n
-            last["gathered"] = gather.gather_packed(dev_pack[:off], torch.from_numpy(lens).to(dev))
+            last["gathered"] = gather.gather_packed(dev_pack[:off], torch.from_numpy(lens).to(comm_dev))
 
     def fence():
         torch.cuda.synchronize()
@@ -132,7 +161,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -147,6 +176,12 @@ def main():
     alg_bytes = (H * W + float(np.mean(lens))) * imgs_per_launch   # 1 B/px read + L/N B/px written
     achieved = alg_bytes / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
 
+    gathered_ok = None
+    if world > 1 and rank == 0:
+        payloads, lens_all = last["gathered"]
+        gathered_ok = (len(payloads) == world and all(int(l.sum()) == p.numel() for p, l in zip(payloads, lens_all)) and
+                       hashlib.sha256(payloads[0][: int(lens_all[0][0])].cpu().numpy().tobytes()).hexdigest() ==
+                       hashlib.sha256(outs[0][: int(lens[0])].tobytes()).hexdigest())
     bit_exact = None
     if rank == 0:
         try:
@@ -170,12 +205,12 @@ def main():
                        if not args.host_inputs else f"{B} x {H}x{W} SYN-1 frames per GPU per step, -n0 -e1, host inputs (PCIe-inclusive)",
                        "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "pinned_host_buffers": host_buffers,
                        "parallelism": f"image-per-GPU x{world}, RCCL gather of streams" if world > 1 else "single GPU"},
-            "bit_exact": bit_exact,
+            "bit_exact": bit_exact, "gathered_ok": gathered_ok,
             "bits_per_pixel": round(8.0 * float(np.mean(lens)) / (H * W), 4),
             "bins_per_pixel": round(bins / (H * W * B), 3),
             "host_coder_Mbins_per_s_per_thread": round(bins / coder_s / 1e6, 1) if coder_s > 0 else None,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": profiled_traffic(dom, imgs_per_launch),
                          "launch_ms": round(per_launch[dom], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                          "images_per_launch": imgs_per_launch},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
