@@ -45,7 +45,7 @@ def cpu_baseline(frames, reps_budget_s=12.0):
 
 
 def profiled_traffic(kernel, images_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate
+    """HBM BYTES per launch of `kernel` from the committed rocprofv3 PMC summary (separate
     --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, FETCH doubled as the gfx950 guide prescribes;
     profiles/*_hbm_traffic.csv, produced by tools/summarize_profile.py), rescaled to this run's
     images per launch.  None when no summary has been committed for that kernel."""
@@ -62,8 +62,7 @@ def profiled_traffic(kernel, images_per_launch):
     prof_ipl = float(meta.get("images_per_launch", 8))
     for row in csv.DictReader(open(files[-1])):
         if row["kernel"].split("(")[0].split("::")[-1] == kernel:
-            return {"GB_per_launch": round(float(row["hbm_MB_per_launch_corrected(2*fetch+write)"]) / 1024 * images_per_launch / prof_ipl, 3),
-                    "source": os.path.basename(files[-1])}
+            return int(float(row["hbm_MB_per_launch_corrected(2*fetch+write)"]) * 1048576 * images_per_launch / prof_ipl)
     return None
 
 
