@@ -1,12 +1,18 @@
-// serial_engine.hip -- raster-serial NBLIC engine: one workgroup per image, model state in LDS.
+// serial_engine.hip -- raster-serial NBLIC engine: one wave per image, model state in LDS.
 //
 // Used for everything that cannot be replayed per key: NBLICdecompress at any
 // setting, near-lossless encode, and the least-squares efforts 2/3.  Mirrors the reference's
 // fused loop (NBLIC.c:749-908) on the device: context table (8 KB), counter trees (32 KB) and
 // re-mappers (60 KB) sit in the CU's 160 KB LDS; the image, the stream and the least-squares
-// row statistics stay in HBM.  Round 1 drives the chain from a single lane -- it is a
-// correctness-first engine whose throughput comes from running many images at once, not from
-// one image; the wave-cooperative least-squares solve is listed in DESIGN.md as next work.
+// row statistics stay in HBM.
+//
+// The whole wave walks the pixel loop with UNIFORM control flow: the coding of a pixel is a
+// dependent chain, so all 64 lanes carry the same scalars (LDS reads broadcast; global stores are
+// issued by lane 0).  What is not a chain is spread over the lanes: the 43/111-element
+// least-squares statistics (update, per-row pre-pass, system assembly) are one or two elements per
+// lane, and the n x n integer elimination (NBLIC.c:112-161) runs one matrix entry per lane -- within
+// an elimination step every entry only reads the pivot row and the pivot column of the previous
+// step, so the lane-parallel order gives the same integers as the reference's nested loops.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -22,6 +28,7 @@ typedef unsigned long long u64;
 constexpr int kLsqMaxN = 10, kLsqMaxM = 1 + kLsqMaxN + kLsqMaxN * kLsqMaxN;
 constexpr int kFb1 = 12, kFb2 = 2, kFb3 = 10, kDecayS = 3, kDecayV = 5;
 constexpr i64 kBiasInit = 8, kBiasMax = 4096, kBiasCoef = 21;
+constexpr int kRowCache = 16384;                 // widest image whose three tap rows fit next to the model in LDS
 
 __device__ __forceinline__ i64 mulw(i64 a, i64 b) { return i64(u64(a) * u64(b)); }    // wrapping, NBLIC.c:139
 __device__ __forceinline__ i64 abs64(i64 v) { return v < 0 ? -v : v; }
@@ -39,6 +46,7 @@ struct DevCoder {
     uint8_t *p, *end;
     uint32_t lo, hi, window;
     bool overflow;
+    bool store;                 // only one lane of the wave writes the stream
 };
 
 template <bool DEC>
@@ -48,7 +56,7 @@ __device__ __forceinline__ int coder_bin(DevCoder &rc, int bin, uint32_t prob) {
     if (bin) rc.hi = cut; else rc.lo = cut + 1;
     while (((rc.lo ^ rc.hi) >> 24) == 0) {
         if (rc.p < rc.end) {
-            if (DEC) rc.window = (rc.window << 8) | *rc.p; else *rc.p = uint8_t(rc.hi >> 24);
+            if (DEC) rc.window = (rc.window << 8) | *rc.p; else if (rc.store) *rc.p = uint8_t(rc.hi >> 24);
         } else { rc.overflow = true; if (DEC) rc.window <<= 8; }
         rc.p++;
         rc.lo <<= 8; rc.hi = (rc.hi << 8) | 0xFFu;
@@ -56,99 +64,152 @@ __device__ __forceinline__ int coder_bin(DevCoder &rc, int bin, uint32_t prob) {
     return bin;
 }
 
-// ---- least-squares predictor (NBLIC.c:112-283); vectors are [s | b(n) | A(n x n)] ----------
-__device__ int lsq_solve(int n, i64 *A, i64 *b) {                        // NBLIC.c:112-161
-    for (int k = 0; k + 1 < n; k++) {
-        int piv = k;
-        for (int i = k + 1; i < n; i++) if (abs64(A[i * n + k]) > abs64(A[piv * n + k])) piv = i;
-        if (piv != k) {
-            i64 t = b[k]; b[k] = b[piv]; b[piv] = t;
-            for (int j = k; j < n; j++) { t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
-        }
-        i64 d = A[k * n + k];
-        if (d == 0) return 0;
-        for (int i = k + 1; i < n; i++) {
-            i64 l = A[i * n + k];
-            A[i * n + k] = 0;
-            if (l == 0) continue;
-            for (int j = k + 1; j < n; j++) A[i * n + j] -= mulw(A[k * n + j], l) / d;
-            b[i] -= mulw(b[k], l) / d;
-        }
-    }
-    for (int k = n - 1; k > 0; k--) {
-        i64 d = A[k * n + k];
-        if (d == 0) return 0;
-        for (int i = 0; i < k; i++) {
-            i64 l = A[i * n + k];
-            A[i * n + k] = 0;
-            if (l != 0) b[i] -= mulw(b[k], l) / d;
-        }
-    }
-    return 1;
+// P(bin==1) = floor(4096 * c1 / (c0 + c1)) (NBLIC.c:621-625) without the integer-divide expansion:
+// both operands are < 2^14, so the float reciprocal estimate is off by less than one and a single
+// remainder check makes it exact.
+__device__ __forceinline__ int prob_one(int c0, int c1) {
+    const int sum = c0 + c1, n = c1 << 12;
+    int q = int(float(n) * __builtin_amdgcn_rcpf(float(sum)));
+    const int r = n - q * sum;
+    q += (r >= sum) - (r < 0);
+    return q;
 }
 
-__device__ int lsq_predict(int n, int m, const i64 *E, const i64 *F, const i64 *vn, i64 bias, i64 *px_q12) {   // :210-239
-    i64 sys[kLsqMaxM];
-    i64 *b = sys + 1, *A = sys + 1 + n;
-    for (int k = 1; k < m; k++) sys[k] = E[k] + F[k];
-    for (int k = 0; k < n; k++) { b[k] += bias * (1 << kFb3); A[k * n + k] += bias * n; }
-    if (!lsq_solve(n, A, b)) return 0;
-    i64 px = i64(kMid) << kFb1;
-    for (int k = 0; k < n; k++) {
-        i64 d = A[k * n + k];
-        px += (mulw(mulw(b[k], vn[k]), 1 << kFb2) + (d >> 1)) / d;
-    }
-    *px_q12 = clip64(px, 0, i64(kMaxVal) << kFb1);
-    return 1;
-}
-
-__device__ void lsq_update(int n, int m, i64 *E, i64 *B, const i64 *vn, int x, i64 s_curr, i64 s_sum) {        // :242-283
-    i64 xc = x - kMid;
-    s_sum = clip64(s_sum + (1 << kFb1), 1 << kFb1, 16 << kFb1);
-    i64 half = s_sum >> 1;
-    for (int k = 0; k < m; k++) {
-        i64 sample;
-        if (k == 0) sample = s_curr;
-        else if (k <= n) sample = (mulw(xc * vn[k - 1], i64(1) << (4 + kFb1 + kFb1)) + half) / s_sum;
-        else { int r = (k - 1 - n) / n, c = (k - 1 - n) % n; sample = (mulw(vn[r] * vn[c], i64(1) << (4 + kFb2 + kFb1)) + half) / s_sum; }
-        int ab = k ? kDecayV : kDecayS;
-        B[k] = decay(B[k], ab) + sample;
-        E[k] = decay(E[k], ab) + B[k];
-    }
-}
-
-// ---- the engine ------------------------------------------------------------------------------
+// ---- the engine's LDS image ------------------------------------------------------------------
 struct Lds {
     int     ctx[kContexts];
     int     c0[kLevels][kTreeNodes], c1[kLevels][kTreeNodes];
     int     count[512][kMapSyms];
     uint8_t rank_of[512][kMapSyms], sym_at[512][kMapSyms];
+    // least squares (efforts 2/3): vectors are [s | b(n) | A(n x n)] (NBLIC.c:213-215)
+    i64     E[kLsqMaxM + 1];                     // statistics of the current row so far
+    i64     D[kLsqMaxM + 1];                     // E + F at the current pixel
+    i64     M[kLsqMaxN][kLsqMaxN + 1];           // augmented system [A | b]
+    i64     vn[kLsqMaxN];
+    i64     term[kLsqMaxN];
+    // the three image rows the causal taps can touch, as a ring (row r lives at r % 3): taps come
+    // from LDS instead of a store -> fence -> load round trip through L2 for every pixel
+    uint8_t rows[3][kRowCache];
 };
 
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }     // one wave per block: orders LDS traffic between lanes
+
+// ---- least-squares predictor, lane-parallel ----------------------------------------------------
+// Q12 prediction from the regularised normal equations (NBLIC.c:210-239 with the solve of :112-161).
+// Uniform result (every lane returns the same values).
+__device__ int lsq_predict_wave(Lds &S, int n, int m, const i64 *F, i64 bias, i64 *px_q12) {
+    const int lane = int(threadIdx.x), cols = n + 1;
+    for (int k = lane; k < m; k += 64) S.D[k] = k ? S.E[k] + F[k] : 0;
+    wave_sync();
+    for (int e = lane; e < n * cols; e += 64) {
+        const int i = e / cols, j = e - i * cols;
+        S.M[i][j] = j == n ? S.D[1 + i] + bias * (1 << kFb3) : S.D[1 + n + i * n + j] + (i == j ? bias * n : 0);
+    }
+    wave_sync();
+    for (int k = 0; k + 1 < n; k++) {                                   // forward elimination, partial pivoting
+        int piv = k;
+        i64 best = abs64(S.M[k][k]);
+        for (int i = k + 1; i < n; i++) { const i64 v = abs64(S.M[i][k]); if (v > best) { best = v; piv = i; } }   // strict: first maximum wins
+        if (piv != k) {
+            for (int j = lane; j < cols; j += 64) { const i64 t = S.M[k][j]; S.M[k][j] = S.M[piv][j]; S.M[piv][j] = t; }
+            wave_sync();
+        }
+        const i64 d = S.M[k][k];
+        if (d == 0) return 0;
+        i64 upd[2]; int cnt = 0;
+        for (int e = lane; e < n * cols; e += 64) {
+            const int i = e / cols, j = e - i * cols;
+            upd[cnt++] = (i > k && j > k) ? S.M[i][j] - mulw(S.M[k][j], S.M[i][k]) / d : 0;
+        }
+        wave_sync();                                                   // every lane has read column k before it is cleared
+        cnt = 0;
+        for (int e = lane; e < n * cols; e += 64) {
+            const int i = e / cols, j = e - i * cols;
+            if (i > k && j > k) S.M[i][j] = upd[cnt]; else if (i > k && j == k) S.M[i][j] = 0;
+            cnt++;
+        }
+        wave_sync();
+    }
+    for (int k = n - 1; k > 0; k--) {                                   // back substitution on b only
+        const i64 d = S.M[k][k];
+        if (d == 0) return 0;
+        for (int i = lane; i < k; i += 64) { S.M[i][n] -= mulw(S.M[k][n], S.M[i][k]) / d; S.M[i][k] = 0; }
+        wave_sync();
+    }
+    for (int k = lane; k < n; k += 64) {
+        const i64 d = S.M[k][k];
+        S.term[k] = (mulw(mulw(S.M[k][n], S.vn[k]), 1 << kFb2) + (d >> 1)) / d;
+    }
+    wave_sync();
+    i64 px = i64(kMid) << kFb1;
+    for (int k = 0; k < n; k++) px += S.term[k];
+    wave_sync();
+    *px_q12 = clip64(px, 0, i64(kMaxVal) << kFb1);
+    return 1;
+}
+
+// fold the newly coded pixel into the running statistics (NBLIC.c:242-283), one or two entries per lane
+__device__ void lsq_update_wave(Lds &S, int n, int m, i64 *B, int x, i64 s_curr, i64 s_sum) {
+    const i64 xc = x - kMid;
+    s_sum = clip64(s_sum + (1 << kFb1), 1 << kFb1, 16 << kFb1);
+    const i64 half = s_sum >> 1;
+    for (int k = int(threadIdx.x); k < m; k += 64) {
+        i64 sample;
+        if (k == 0) sample = s_curr;
+        else if (k <= n) sample = (mulw(xc * S.vn[k - 1], i64(1) << (4 + kFb1 + kFb1)) + half) / s_sum;
+        else { const int r = (k - 1 - n) / n, c = (k - 1 - n) - r * n; sample = (mulw(S.vn[r] * S.vn[c], i64(1) << (4 + kFb2 + kFb1)) + half) / s_sum; }
+        const int ab = k ? kDecayV : kDecayS;
+        const i64 b = decay(B[k], ab) + sample;
+        B[k] = b;
+        S.E[k] = decay(S.E[k], ab) + b;
+    }
+    wave_sync();
+}
+
+// once per row: right-to-left accumulation of the row-above statistics (NBLIC.c:186-204); a lane owns a channel
+__device__ void lsq_row_prepare_wave(int m, i64 *Frow, const i64 *Brow, int w) {
+    for (int k = int(threadIdx.x); k < m; k += 64) {
+        const int ab = k ? kDecayV : kDecayS;
+        i64 carry = 0;
+        for (int j = w - 1; j >= 0; j--) {
+            const i64 f = carry + Brow[size_t(j) * m + k];
+            Frow[size_t(j) * m + k] = f;
+            carry = decay(f, ab);
+        }
+    }
+    __threadfence_block();
+    wave_sync();
+}
+
+// ---- the engine --------------------------------------------------------------------------------
 template <bool DEC>
 __device__ void run_engine(const SerialArgs &a, Lds &S) {
     const int w = a.w, h = a.h, near = a.near, k_step = a.k_step;
     const int n = a.effort == 2 ? 6 : (a.effort == 3 ? 10 : 0);                    // N_LIST, NBLIC.c:88
     const int m = 1 + n + n * n;
+    const bool lane0 = threadIdx.x == 0;
     uint8_t *img = a.img;
     i64 *Brow = a.stats, *Frow = a.stats + size_t(w) * m;
-    i64 E[kLsqMaxM], vn[kLsqMaxN];
     i64 bias = kBiasInit;
 
     DevCoder rc{a.stream + kHeaderBytes, a.stream + a.stream_cap, 0u, 0xFFFFFFFFu, 0u, false};
+    rc.store = lane0;
     if (DEC) for (int k = 0; k < 4; k++) rc.window = (rc.window << 8) | *rc.p++;
 
-    auto pix = [&](int r, int c) { return int(img[size_t(r) * size_t(w) + size_t(c)]); };
+    const bool cached = w <= kRowCache;
+    auto pix = [&](int r, int c) {
+        return cached ? int(S.rows[r % 3][c]) : int(img[size_t(r) * size_t(w) + size_t(c)]);
+    };
 
     for (int i = 0; i < h; i++) {
         int err = 0;
-        if (n > 0) {                                                               // NBLIC.c:817-820, 186-204
-            for (int k = 0; k < m; k++) E[k] = 0;
-            for (int j = w - 1; j >= 0; j--)
-                for (int k = 0; k < m; k++) {
-                    i64 carry = (j == w - 1) ? 0 : decay(Frow[size_t(j + 1) * m + k], k ? kDecayV : kDecayS);
-                    Frow[size_t(j) * m + k] = carry + Brow[size_t(j) * m + k];
-                }
+        if (cached && !DEC) {                                                      // encoder: the row's ORIGINAL pixels; each is replaced by its reconstruction once coded
+            for (int c = int(threadIdx.x); c < w; c += 64) S.rows[i % 3][c] = img[size_t(i) * size_t(w) + size_t(c)];
+            wave_sync();
+        }
+        if (n > 0) {                                                               // NBLIC.c:817-820
+            for (int k = int(threadIdx.x); k < m; k += 64) S.E[k] = 0;
+            lsq_row_prepare_wave(m, Frow, Brow, w);
         }
         for (int j = 0; j < w; j++) {
             Taps t = sample_taps(pix, w, i, j);
@@ -156,15 +217,20 @@ __device__ void run_engine(const SerialArgs &a, Lds &S) {
             int ok1 = 0, ok2 = 0, px0;
             i64 *B = nullptr, *F = nullptr;
             if (n > 0) {                                                           // NBLIC.c:831-846
-                const int order[kLsqMaxN] = {t.a, t.b, t.c, t.d, t.e, t.f, t.t, t.h, t.q, t.g};
-                for (int k = 0; k < n; k++) vn[k] = order[k] - kMid;
+                if (threadIdx.x < unsigned(n)) {
+                    const int order[kLsqMaxN] = {t.a, t.b, t.c, t.d, t.e, t.f, t.t, t.h, t.q, t.g};
+                    int v = order[0];
+                    for (int k = 1; k < kLsqMaxN; k++) if (int(threadIdx.x) == k) v = order[k];
+                    S.vn[threadIdx.x] = v - kMid;
+                }
+                wave_sync();
                 B = Brow + size_t(j) * m; F = Frow + size_t(j) * m;
                 b1 = bias * kBiasCoef / (kBiasCoef + 1);
                 b2 = bias * (kBiasCoef + 1) / kBiasCoef;
                 b1 = clip64(clip64(b1, -1, bias - 1), 0, kBiasMax);
                 b2 = clip64(clip64(b2, bias + 1, kBiasMax + 1), 0, kBiasMax);
-                ok1 = lsq_predict(n, m, E, F, vn, b1, &p1);
-                ok2 = lsq_predict(n, m, E, F, vn, b2, &p2);
+                ok1 = lsq_predict_wave(S, n, m, F, b1, &p1);
+                ok2 = lsq_predict_wave(S, n, m, F, b2, &p2);
             }
             if (ok1) px0 = int((p1 + (1 << (kFb1 - 1))) >> kFb1);
             else { px0 = predict(t); p1 = i64(px0) << kFb1; }
@@ -177,14 +243,17 @@ __device__ void run_engine(const SerialArgs &a, Lds &S) {
 
             auto step = [&](int qu, int qv, int node, int bin) {                   // NBLIC.c:628-637
                 int u0 = S.c0[qu][node], u1 = S.c1[qu][node], v0 = S.c0[qv][node], v1 = S.c1[qv][node];
-                int prob = mix_prob(counter_p1(u0, u1), counter_p1(v0, v1), L.qw);
+                int prob = mix_prob(prob_one(u0, u1), prob_one(v0, v1), L.qw);
                 bin = coder_bin<DEC>(rc, bin, uint32_t(prob));
                 Counter cu{u0, u1};
                 counter_add(cu, bin, kWeightOne - L.qw);
+                if (qu == qv) counter_add(cu, bin, L.qw);                          // same counter takes both weights
                 S.c0[qu][node] = cu.c0; S.c1[qu][node] = cu.c1;
-                Counter cv{S.c0[qv][node], S.c1[qv][node]};                        // re-read: qu may equal qv
-                counter_add(cv, bin, L.qw);
-                S.c0[qv][node] = cv.c0; S.c1[qv][node] = cv.c1;
+                if (qu != qv) {
+                    Counter cv{v0, v1};
+                    counter_add(cv, bin, L.qw);
+                    S.c0[qv][node] = cv.c0; S.c1[qv][node] = cv.c1;
+                }
                 return bin;
             };
 
@@ -198,33 +267,41 @@ __device__ void run_engine(const SerialArgs &a, Lds &S) {
             }
             if (y < kMapSyms) {                                                    // NBLIC.c:497-523
                 int z = S.rank_of[mk][y];
-                int c = ++S.count[mk][z];
-                if (z > 0 && S.count[mk][z - 1] < c) {
-                    int other = S.sym_at[mk][z - 1];
-                    S.count[mk][z] = S.count[mk][z - 1]; S.count[mk][z - 1] = c;
+                int c = S.count[mk][z] + 1;
+                int c_up = z > 0 ? S.count[mk][z - 1] : 0x7FFFFFFF;
+                int other = z > 0 ? int(S.sym_at[mk][z - 1]) : 0;
+                wave_sync();                                                       // every lane has read before any lane writes
+                if (c_up < c) {
+                    S.count[mk][z] = c_up; S.count[mk][z - 1] = c;
                     S.sym_at[mk][z] = uint8_t(other); S.sym_at[mk][z - 1] = uint8_t(y);
                     S.rank_of[mk][y] = uint8_t(z - 1); S.rank_of[mk][other] = uint8_t(z);
+                } else {
+                    S.count[mk][z] = c;
                 }
             }
             int xr = symbol_to_pixel(y, px, sign, near);
-            img[size_t(i) * size_t(w) + size_t(j)] = uint8_t(xr);
+            if (lane0) img[size_t(i) * size_t(w) + size_t(j)] = uint8_t(xr);
             err = clip_err(xr, px0);
             S.ctx[adr] = bias_update(v, err);
+            if (cached) S.rows[i % 3][j] = uint8_t(xr);
+            else __threadfence_block();
+            wave_sync();                                                           // the pixel is visible to every lane's next taps
 
             if (n > 0) {                                                           // NBLIC.c:882-893
                 i64 xq = i64(xr) << kFb1;
                 i64 s_curr = abs64(p1 - xq);
-                i64 s_sum = (E[0] + F[0]) + s_curr * kDecayS / (kDecayS - 1);
-                lsq_update(n, m, E, B, vn, xr, s_curr, s_sum);
+                i64 s_sum = (S.E[0] + F[0]) + s_curr * kDecayS / (kDecayS - 1);
+                wave_sync();
+                lsq_update_wave(S, n, m, B, xr, s_curr, s_sum);
                 if (ok1 && ok2) bias = (abs64(p1 - xq) > abs64(p2 - xq)) ? b2 : b1;
             }
         }
     }
     if (!DEC) for (int k = 0; k < 4; k++) {                                        // NBLIC.c:576-586
-        if (rc.p < rc.end) *rc.p = uint8_t(rc.lo >> 24); else rc.overflow = true;
+        if (rc.p < rc.end) { if (lane0) *rc.p = uint8_t(rc.lo >> 24); } else rc.overflow = true;
         rc.p++; rc.lo <<= 8;
     }
-    *a.len_out = rc.overflow ? -1L : long(rc.p - a.stream);
+    if (lane0) *a.len_out = rc.overflow ? -1L : long(rc.p - a.stream);
 }
 
 __global__ void __launch_bounds__(64) k_serial_codec(SerialArgs a) {
@@ -236,7 +313,6 @@ __global__ void __launch_bounds__(64) k_serial_codec(SerialArgs a) {
         (&S.count[0][0])[k] = 2 * (kMapSyms - 1 - s); (&S.rank_of[0][0])[k] = uint8_t(s); (&S.sym_at[0][0])[k] = uint8_t(s);
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
     if (a.decode) run_engine<true>(a, S); else run_engine<false>(a, S);
 }
 

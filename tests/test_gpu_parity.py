@@ -212,3 +212,20 @@ def test_config3_kodak_shaped_batch(gpu_ctx, oracle):
     assert len(set(got)) == 24
     for g, im in zip(gotq, imgs[:6] + imgs[-3:]):
         assert g == oracle.qencode(im)
+
+
+@pytest.mark.parametrize("key", ["syn1s1_256x256_n0_e2", "syn1s1_256x256_n0_e3", "syn1s1_256x256_n2_e2", "syn1s1_512x512_n2_e1"])
+def test_serial_modes_moderate_sizes(pkg, golden, oracle, key):
+    """Stand-ins for BASELINE configs 4/5 (raster-serial modes) at sizes the serial engine finishes
+    in seconds: stream and reconstruction hashes from the compiled reference, then a GPU decode."""
+    from oracle.oracle import syn1
+    manifest, _ = golden
+    m = manifest["large"][key]
+    name, dims, n, e = key.split("_")
+    h, w = map(int, dims.split("x"))
+    img = syn1(h, w, int(name[5:]))
+    s, rec, _, _ = pkg.compress(img, int(n[1:]), int(e[1:]))
+    assert (len(s), sha(s)) == (m["len"], m["sha256"])
+    assert sha(rec.tobytes()) == m["recon_sha256"]
+    d = pkg.decompress(s)
+    assert d is not None and np.array_equal(d[0], rec) and d[1:] == (int(n[1:]), int(e[1:]))
