@@ -229,3 +229,31 @@ def test_serial_modes_moderate_sizes(pkg, golden, oracle, key):
     assert sha(rec.tobytes()) == m["recon_sha256"]
     d = pkg.decompress(s)
     assert d is not None and np.array_equal(d[0], rec) and d[1:] == (int(n[1:]), int(e[1:]))
+
+
+def test_extreme_shapes_and_buffer_growth(gpu_ctx, oracle):
+    """Maximum width / height (65535, NBLIC.h:29-30), and a noise frame whose 9.5 bins/px exceed the
+    6 bins/px the event buffers are provisioned for (they are re-sized from the measured total)."""
+    from oracle.oracle import syn1
+    imgs = [syn1(1, 65535, 3), syn1(65535, 1, 4), syn1(3, 40000, 5), inputs.noise(1024, 1024, 11)]
+    got = gpu_ctx.encode_batch(imgs)
+    for k, (img, g) in enumerate(zip(imgs, got)):
+        assert g == oracle.encode(img, 0, 1)[0], k
+    gq = gpu_ctx.qencode_batch(imgs[:3])
+    for img, g in zip(imgs[:3], gq):
+        assert g == oracle.qencode(img)
+
+
+def test_size_limits(pkg, gpu_ctx):
+    # the reference refuses > 100,000,000 pixels (NBLIC.c:726): so do the drop-in symbols and the batch API
+    big = np.zeros((1, 1), np.uint8)
+    import ctypes as C
+    lib = pkg.load_library()
+    out = np.empty(64, np.uint8)
+    n, e = C.c_int(0), C.c_int(1)
+    u8p = C.POINTER(C.c_uint8)
+    assert lib.NBLICcompress(0, out.ctypes.data_as(u8p), big.ctypes.data_as(u8p), 10001, 10000, C.byref(n), C.byref(e)) == -1
+    assert lib.NBLICcompress(0, out.ctypes.data_as(u8p), big.ctypes.data_as(u8p), 0, 5, C.byref(n), C.byref(e)) == -1
+    assert lib.QNBLICcompress(out.ctypes.data_as(C.POINTER(C.c_uint16)), big.ctypes.data_as(u8p), 70000, 1) == -1
+    with pytest.raises(RuntimeError):
+        gpu_ctx.encode_ptrs([big.ctypes.data], [(10001, 10000)], False, [np.empty(64, np.uint8)])
