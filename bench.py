@@ -18,6 +18,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The pipeline keeps 6 group streams + 4 copy streams + 1 serial-engine stream busy.  The HIP runtime
+# multiplexes streams onto 4 hardware queues by default, which puts the coder threads' copies
+# behind other groups' kernels; it reads this when it initialises, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy
 
@@ -71,13 +75,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (the pipeline's fill and drain, ~0.1 s + ~0.8 s, are inside every step)")
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--coders", type=int, default=0, help="host range-coder threads per GPU (0 = CPU share)")
     ap.add_argument("--slots", type=int, default=0, help="images in flight per GPU (0 = min(batch, 48))")
     ap.add_argument("--groups", type=int, default=6, help="launch groups the images in flight are split into")
-    ap.add_argument("--host-buffers", type=int, default=0, help="pinned host buffers for coded bins (0 = max(2*slots, batch))")
+    ap.add_argument("--host-buffers", type=int, default=0, help="coded-bin buffers in HBM between the GPU and the coder threads (0 = slots + 16*coders + 32)")
     ap.add_argument("--host-inputs", action="store_true", help="hand host buffers over (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 path be rehearsed with every rank on one GPU")
@@ -116,7 +120,7 @@ def main():
         frames = list(ex.map(lambda k: pkg.syn1(H, W, seed=rank * B + k + 1), range(B)))
     dev_frames = [torch.from_numpy(f).to(dev) for f in frames]
     torch.cuda.synchronize()
-    host_buffers = args.host_buffers or max(slots + 16, min(B, 96))
+    host_buffers = args.host_buffers or min(B + 16, slots + 16 * coders + 32)   # groups in flight + every thread's sixteen + a queue
     ctx = pkg.Context(device=gpu, n_slots=slots, n_coders=coders, n_groups=max(1, min(args.groups, slots)),
                       n_host_buffers=host_buffers)
     ctx.enable_timing(True)
@@ -202,7 +206,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{B} x {H}x{W} SYN-1 gray frames per GPU per step, -n0 -e1, inputs resident in HBM"
                        if not args.host_inputs else f"{B} x {H}x{W} SYN-1 frames per GPU per step, -n0 -e1, host inputs (PCIe-inclusive)",
-                       "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "pinned_host_buffers": host_buffers,
+                       "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "coded_bin_buffers_in_hbm": host_buffers,
                        "parallelism": f"image-per-GPU x{world}, RCCL gather of streams" if world > 1 else "single GPU"},
             "bit_exact": bit_exact, "gathered_ok": gathered_ok,
             "bits_per_pixel": round(8.0 * float(np.mean(lens)) / (H * W), 4),

@@ -46,7 +46,7 @@ struct E1Buffers {
     uint8_t  *blk_ok;        // n/4096+2048   1 = the block's warm-up copies met (its output is exact)
     uint32_t *qhist;         // 12 * 256      QNBLIC symbol histograms per activity level
     unsigned long long *dbg_out;   // 4096 words of in-kernel cycle stamps, written only when E1Job::dbg & 8
-    uint32_t *win_base;      // 4097          first window record of every counter chain (+ total)
+    uint32_t *win_base;      // 4097 + 4096   first window record of every counter chain (+ total); chain keys, longest first
     uint32_t *win_recs;      // 24 words per 512-touch window: entry state + halving epochs (kernels_e1.hip WinRec)
     uint16_t *coded;         // ev_cap        prob | bin<<15 for the host range coder
 };

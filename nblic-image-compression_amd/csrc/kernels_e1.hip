@@ -96,6 +96,17 @@ __device__ __forceinline__ uint32_t prob_one(int c1, int sum) {
 }
 
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); }
+// v_writelane_b32: lane `l` of the result takes the uniform `value`, the other lanes keep `old`
+template <int L>
+__device__ __forceinline__ int write_lane(int value, int old) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(L));
+    return old;
+}
+// three registers at one run-time lane (the lane select goes through m0: one SGPR operand per VOP)
+__device__ __forceinline__ void write_lane3(int l, int a, int b, int c, int &ra, int &rb, int &rc) {
+    asm("s_mov_b32 m0, %6\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+        : "+v"(ra), "+v"(rb), "+v"(rc) : "s"(a), "s"(b), "s"(c), "s"(l) : "m0");
+}
 
 // Lane-per-key streaming: each of the wave's 64 lanes owns one run of 2-byte records
 // in[r .. end) and must replace every record by step(record) in order.  Per round the wave
@@ -660,37 +671,60 @@ __device__ __forceinline__ void window_prefix(const u32x4 w, uint32_t window, ui
     for (int k = 0; k < kTpl; k++) { tin[k] += lane_t; oin[k] += lane_o; }
 }
 
-// windows per chain -> exclusive scan -> win_base[4097]; one 1024-thread block per job
+// windows per chain -> exclusive scan -> win_base[0..4096]; win_base[4097..] = the chain keys
+// ordered longest first (by power-of-two length class), so the kernel's critical path -- the
+// hottest chain -- starts in the first round of workgroups.  One 1024-thread block per job.
 __global__ void __launch_bounds__(1024) k_plan_windows(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t part[16];
+    __shared__ uint32_t klass[32];
     const E1Job &J = jobs[blockIdx.y];
     const auto table = gptr(J.b.table); const auto win_base = gptr(J.b.win_base);
     const uint32_t total = gptr(J.b.totals)[3];
     const int nseg = J.pe.nseg;
-    uint32_t cnt[4], sum = 0;
+    if (threadIdx.x < 32) klass[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t cnt[4], sum = 0; int cls[4];
     for (int k = 0; k < 4; k++) {
         int key = int(threadIdx.x) * 4 + k;
         uint32_t start = table[size_t(key) * nseg];
         uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * nseg] : total;
         cnt[k] = end > start ? (end - (start & ~7u) + kWin - 1) / kWin : 0u;
         sum += cnt[k];
+        cls[k] = end > start ? __clz(int(end - start)) : 31;        // 0 = longest
+        atomicAdd(&klass[cls[k]], 1u);
     }
     uint32_t incl = wave_scan_incl(sum);
     if (lane_id() == 63) part[threadIdx.x >> 6] = incl;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int c = 0; c < 32; c++) { uint32_t v = klass[c]; klass[c] = run; run += v; }
+    }
     uint32_t pre = incl - sum;
     for (int wv = 0; wv < int(threadIdx.x >> 6); wv++) pre += part[wv];
     for (int k = 0; k < 4; k++) { win_base[threadIdx.x * 4 + k] = pre; pre += cnt[k]; }
     if (threadIdx.x == 1023) win_base[4096] = pre;
+    __syncthreads();
+    for (int k = 0; k < 4; k++) win_base[4097 + atomicAdd(&klass[cls[k]], 1u)] = threadIdx.x * 4 + k;
 }
 
+// One lone wave issues at most one instruction every four cycles and pays extra for every
+// VALU -> SALU hand-off, so this kernel is written for INSTRUCTION COUNT:
+//   * a touch's weights sum to <= 32, so a window's prefix of (total weight, weight to bin 1)
+//     fits one packed word (total << 16 | ones); one add / one DPP scan serves both;
+//   * the record is assembled in three registers with v_writelane (lane l = words 3l..3l+2) and
+//     stored once per window;
+//   * a touch that crosses the limit halves the counter exactly once (the sum drops to ~4100 and
+//     the second weight is <= 32), which removes the second conditional halving from the scalar
+//     arithmetic;
+//   * the crossing touch's prefix and payload are fetched with a uniform register index.
 __global__ void __launch_bounds__(64) k_counter_epochs(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
     const auto tin_g = gptr(J.b.tin); const auto table = gptr(J.b.table);
     const auto cnt_state = (NB_GLOBAL i32x2 *)gptr(J.b.cnt_state);
     const auto recs = gptr(J.b.win_recs);
     const SegPlan plan = J.pe;
-    const int key = int(blockIdx.x);
+    const int key = int(gptr(J.b.win_base)[4097 + blockIdx.x]);
     const int lane = int(threadIdx.x);
     const uint32_t start = table[size_t(key) * plan.nseg];
     const uint32_t end = key + 1 < 4096 ? table[size_t(key + 1) * plan.nseg] : gptr(J.b.totals)[3];
@@ -702,74 +736,102 @@ __global__ void __launch_bounds__(64) k_counter_epochs(const E1Job *__restrict__
     const int dbg = J.dbg;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const uint32_t first_window = start & ~7u;
-    // Three windows in flight: the chain is serial, so its memory latency must be covered by
-    // depth.  The loop is unrolled by three over NAMED buffers -- rotating one register set at the
+    int r0 = 0, r1 = int(start), r2 = int(end);                      // record words; lane 0 keeps (window, start, end)
+    unsigned n_halv_all = 0;
+    // Four windows in flight: the chain is serial, so its memory latency must be covered by
+    // depth.  The loop is unrolled by four over NAMED buffers -- rotating one register set at the
     // back edge makes the compiler wait for the load it has only just issued.
     auto process = [&](const u32x4 w, const uint32_t window) {
-        uint32_t pay[kTpl]; int tin[kTpl], oin[kTpl], lane_t, lane_o;
-        window_prefix(w, window, start, end, lane, pay, tin, oin, lane_t, lane_o);
-        const auto rec = recs + size_t(rec_i) * 24;
-        int vb_s = base_s, vb_1 = base_1;                           // uniform virtual base of the current epoch
-        int n_halv = 0;
-        if (lane == 0) {
-            ((NB_GLOBAL u32x4 *)rec)[0] = u32x4{window, start, end, uint32_t(vb_s)};
-            rec[4] = uint32_t(vb_1);
+        // v[0..8]: lane-local packed prefix BEFORE touch k (v[8] = lane total); v[9..12]: the raw payload words
+        // (sixteen entries: the indexed read is modelled as touching a whole 16-register tuple, and a
+        // 13-entry array would let that tuple overlap the registers of a window still being loaded)
+        uint32_t v[16];
+        v[13] = v[14] = v[15] = 0;
+        v[9] = w.x; v[10] = w.y; v[11] = w.z; v[12] = w.w;
+        uint32_t pt[kTpl];
+#pragma unroll
+        for (int k = 0; k < kTpl; k++) {
+            const uint32_t p = v[9 + (k >> 1)] >> (16 * (k & 1));
+            const uint32_t tot = (p & 63u) + ((p >> 6) & 63u);
+            pt[k] = (tot << 16) | (((p >> 12) & 1u) ? tot : 0u);
         }
+        if (window < start || window + kWin > end) {                 // chain edge (wave-uniform): mask foreign slots
+            const uint32_t first = window + uint32_t(lane) * kTpl;
+#pragma unroll
+            for (int k = 0; k < kTpl; k++) if (first + k < start || first + k >= end) pt[k] = 0;
+        }
+        v[0] = 0;
+#pragma unroll
+        for (int k = 0; k < kTpl; k++) v[k + 1] = v[k] + pt[k];
+        const uint32_t incl = wave_scan_incl_dpp(v[kTpl]);
+        const uint32_t lane_ex = incl - v[kTpl];
+        int vb_s = base_s, vb_1 = base_1;                            // uniform virtual base of the current epoch
+        int n_halv = 0;
+        r0 = write_lane<0>(int(window), r0);
+        r0 = write_lane<1>(vb_s, r0);
+        r1 = write_lane<1>(vb_1, r1);
 #pragma unroll 1
         for (;;) {
             // Prefixes are non-decreasing, so "first touch that lifts the sum over the limit" is a
-            // rank query: lanes wholly below the threshold form a prefix of the wave.
-            const int thr = kCountLimit - vb_s;
-            const int H = __popcll(__ballot(tin[kTpl - 1] <= thr));
+            // rank query: lanes wholly below the threshold form a prefix of the wave.  The packed
+            // compare works on the high half; the low half of the threshold is all ones.
+            const uint32_t thr = (uint32_t(kCountLimit - vb_s) << 16) | 0xFFFFu;
+            const int H = __popcll(__ballot(incl <= thr));
             if (H >= 64) break;
+            const uint32_t d = thr - lane_ex;                        // meaningful in lane H, where lane_ex <= thr
             int below = 0;
 #pragma unroll
-            for (int k = 0; k < kTpl; k++) below += int(tin[k] <= thr);
-            // every lane picks, branch-free, the exclusive prefixes and payload of ITS touch number `below`;
-            // only lane H's pick is read
-            int sel_t = lane_t, sel_o = lane_o; uint32_t sel_p = pay[0];
-#pragma unroll
-            for (int k = 1; k < kTpl; k++) { const bool is = below == k; sel_t = is ? tin[k - 1] : sel_t; sel_o = is ? oin[k - 1] : sel_o; sel_p = is ? pay[k] : sel_p; }
-            const int hk = __builtin_amdgcn_readlane(below, H);
-            const int t_ex = __builtin_amdgcn_readlane(sel_t, H), o_ex = __builtin_amdgcn_readlane(sel_o, H);
-            const uint32_t hp = uint32_t(__builtin_amdgcn_readlane(int(sel_p), H));
-            const int hb = int((hp >> 12) & 1), hw = int(hp & 63) + int((hp >> 6) & 63);
-            // counter_add twice (NBLIC.c:606-618) without branches; the second weight may be 0
-            int c1 = vb_1 + o_ex, c0 = vb_s + t_ex - c1;
-            const int a1 = int(hp & 63), a2 = int((hp >> 6) & 63);
-            c1 += hb ? a1 : 0; c0 += hb ? 0 : a1;
-            int hv = int(c0 + c1 > kCountLimit); c0 = (c0 + hv) >> hv; c1 = (c1 + hv) >> hv;
-            c1 += hb ? a2 : 0; c0 += hb ? 0 : a2;
-            hv = int(c0 + c1 > kCountLimit); c0 = (c0 + hv) >> hv; c1 = (c1 + hv) >> hv;
-            vb_s = c0 + c1 - (t_ex + hw);                           // new base = state after it minus its inclusive prefix
-            vb_1 = c1 - (o_ex + (hb ? hw : 0));
-            if (lane == 0) {
-                const int slot = n_halv < kMaxHalv ? n_halv : kMaxHalv;
-                rec[6 + 3 * slot] = uint32_t(H * kTpl + hk + 1);
-                rec[7 + 3 * slot] = uint32_t(vb_s);
-                rec[8 + 3 * slot] = uint32_t(vb_1);
-            }
+            for (int k = 1; k <= kTpl; k++) below += int(v[k] <= d);
+            const int hk = __builtin_amdgcn_readlane(below, H);      // < 8 in lane H
+            const uint32_t ex = read_lane(lane_ex + v[hk], H);
+            const uint32_t hx = read_lane(v[9 + (hk >> 1)], H) >> (16 * (hk & 1));
+            const int t_ex = int(ex >> 16), o_ex = int(ex & 0xFFFFu);
+            const int a1 = int(hx & 63u), hw = a1 + int((hx >> 6) & 63u);
+            const int one = -int((hx >> 12) & 1u);                   // all ones when the bin is 1
+            // counter_add for both weights (NBLIC.c:606-618): exactly one of them halves
+            const int s0 = vb_s + t_ex;
+            int c1 = vb_1 + o_ex, c0 = s0 - c1;
+            const int before = (s0 + a1 > kCountLimit) ? a1 : hw, after = hw - before;
+            c1 += before & one; c0 += before & ~one;
+            c1 = (c1 + 1) >> 1; c0 = (c0 + 1) >> 1;
+            c1 += after & one; c0 += after & ~one;
+            vb_s = c0 + c1 - (t_ex + hw);                            // new base = state after it minus its inclusive prefix
+            vb_1 = c1 - (o_ex + (hw & one));
+            const int slot = 2 + (n_halv < kMaxHalv ? n_halv : kMaxHalv);
+            write_lane3(slot, H * kTpl + hk + 1, vb_s, vb_1, r0, r1, r2);
             n_halv++;
         }
-        if (lane == 0) rec[5] = uint32_t(n_halv);
-        base_s = vb_s + __builtin_amdgcn_readlane(tin[kTpl - 1], 63);
-        base_1 = vb_1 + __builtin_amdgcn_readlane(oin[kTpl - 1], 63);
+        r2 = write_lane<1>(n_halv, r2);
+        if (lane < 8) {
+            const auto rec = recs + size_t(rec_i) * 24 + lane * 3;
+            rec[0] = uint32_t(r0); rec[1] = uint32_t(r1); rec[2] = uint32_t(r2);
+        }
+        const uint32_t whole = read_lane(incl, 63);
+        base_s = vb_s + int(whole >> 16);
+        base_1 = vb_1 + int(whole & 0xFFFFu);
+        n_halv_all += unsigned(n_halv);
         rec_i++;
     };
-    auto fetch = [&](uint32_t window) { return window < end ? in_w[(window >> 3) + lane] : u32x4{0u, 0u, 0u, 0u}; };
-    u32x4 b0 = fetch(first_window), b1 = fetch(first_window + kWin), b2 = fetch(first_window + 2 * kWin);
-    for (uint32_t window = first_window; window < end; window += 3 * kWin) {
+    // The prefetch is UNCONDITIONAL (past the chain it re-reads the last window): a load inside a
+    // branch makes the number of requests in flight unknown to the compiler, which then waits for
+    // all of them -- including the one it has only just issued -- before every window.
+    const uint32_t last_window = first_window + ((end - 1 - first_window) / kWin) * kWin;
+    auto fetch = [&](uint32_t window) { return in_w[(min(window, last_window) >> 3) + lane]; };
+    u32x4 b0 = fetch(first_window), b1 = fetch(first_window + kWin), b2 = fetch(first_window + 2 * kWin), b3 = fetch(first_window + 3 * kWin);
+    for (uint32_t window = first_window; window < end; window += 4 * kWin) {
         process(b0, window);
-        b0 = fetch(window + 3 * kWin);
+        b0 = fetch(window + 4 * kWin);
         if (window + kWin < end) process(b1, window + kWin);
-        b1 = fetch(window + 4 * kWin);
+        b1 = fetch(window + 5 * kWin);
         if (window + 2 * kWin < end) process(b2, window + 2 * kWin);
-        b2 = fetch(window + 5 * kWin);
+        b2 = fetch(window + 6 * kWin);
+        if (window + 3 * kWin < end) process(b3, window + 3 * kWin);
+        b3 = fetch(window + 7 * kWin);
     }
     if (lane == 0) cnt_state[key] = i32x2{base_s - base_1, base_1};
     if ((dbg & 8) && lane == 0 && end - start > 100000u) {
         const auto d = gptr(J.b.dbg_out) + 256 + (key & 255) * 4;
-        d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = end - start; d[2] = rec_i - gptr(J.b.win_base)[key]; d[3] = uint32_t(key);
+        d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = end - start; d[2] = rec_i - gptr(J.b.win_base)[key]; d[3] = n_halv_all;
     }
 }
 

@@ -23,6 +23,7 @@
 #include "../../include/nblic_amd.h"
 #include "kernels_e1.h"
 #include "model.h"
+#include "range_coder.h"
 #include "serial_engine.h"
 
 struct nblic_amd_ctx;
@@ -39,31 +40,42 @@ namespace nblic {
     } while (0)
 
 // ---- S6: 32-bit carry-less binary range coder (NBLIC.c:527-586), encoder side ------------
-// coded[r] = prob (12 bit, P(bin==1)) | bin << 15.  Bin 1 takes the lower part of [lo, hi].
-// Returns the number of bytes written, or SIZE_MAX if `cap` bytes were not enough.
-size_t range_code(const uint16_t *coded, size_t n, uint8_t *out, size_t cap) {
-    uint32_t lo = 0, hi = 0xFFFFFFFFu;
-    uint8_t *p = out, *end = out + (cap < 4 ? 0 : cap - 4);          // keep room for the flush
-    if (cap < 4) return SIZE_MAX;
+// (range_coder.h: resumable, because the coder threads stream the bins from HBM in chunks)
+void RangeScalar::feed(const uint16_t *coded, size_t n) {
+    if (overflow) return;
+    uint32_t l = lo, h = hi;
+    uint8_t *q = p;
     for (size_t r = 0; r < n; r++) {
         uint32_t e = coded[r];
-        uint32_t cut = lo + uint32_t((uint64_t(hi - lo) * (e & 0xFFFu)) >> 12);
+        uint32_t cut = l + uint32_t((uint64_t(h - l) * (e & 0xFFFu)) >> 12);
         bool one = (e >> 15) != 0;
-        hi = one ? cut : hi;
-        lo = one ? lo : cut + 1;
-        while (((lo ^ hi) >> 24) == 0) {
-            if (p == end) return SIZE_MAX;
-            *p++ = uint8_t(hi >> 24);
-            lo <<= 8;
-            hi = (hi << 8) | 0xFFu;
+        h = one ? cut : h;
+        l = one ? l : cut + 1;
+        while (((l ^ h) >> 24) == 0) {
+            if (q == end) { overflow = true; return; }
+            *q++ = uint8_t(h >> 24);
+            l <<= 8;
+            h = (h << 8) | 0xFFu;
         }
     }
-    for (int k = 0; k < 4; k++) { *p++ = uint8_t(lo >> 24); lo <<= 8; }
+    lo = l; hi = h; p = q;
+}
+
+size_t RangeScalar::finish() {
+    if (overflow) return SIZE_MAX;
+    uint32_t l = lo;
+    for (int k = 0; k < 4; k++) { *p++ = uint8_t(l >> 24); l <<= 8; }
     return size_t(p - out);
 }
 
-bool have_avx512();
-void range_code_x8(const uint16_t *const *coded, const size_t *n, int count, uint8_t *const *outs, const size_t *caps, size_t *lens);
+// Returns the number of bytes written, or SIZE_MAX if `cap` bytes were not enough.
+size_t range_code(const uint16_t *coded, size_t n, uint8_t *out, size_t cap) {
+    if (cap < 4) return SIZE_MAX;
+    RangeScalar r;
+    r.begin(out, cap);
+    r.feed(coded, n);
+    return r.finish();
+}
 
 long q_entropy_encode(uint16_t *out, size_t cap_words, int h, int w, const uint16_t *qy, const uint32_t *hist_in);
 
@@ -79,11 +91,17 @@ bool size_ok(int h, int w, long max_px) {                                       
     return h > 0 && w > 0 && h <= NBLIC_MAX_HEIGHT && w <= NBLIC_MAX_WIDTH && long(h) * long(w) <= max_px;
 }
 
-// ---- host side of an image between the GPU and the coder threads ---------------------------
-struct HostBuf { uint16_t *p = nullptr; size_t cap = 0; };         // pinned; receives one image's coded bins
+// ---- an image between the GPU and the coder threads ----------------------------------------
+// The backlog lives in HBM: a finished image's coded bins stay in a device buffer until a coder
+// thread streams them to the host chunk by chunk (its own small pinned ring), so the pinned host
+// memory is per THREAD, not per image, and the GPU never waits for host buffers.
+struct CodedBuf { uint16_t *p = nullptr; size_t cap = 0; };        // device; one image's coded bins (QNBLIC: pairs + histograms)
+constexpr size_t kChunkBins = size_t(1) << 20;                     // bins per lane per chunk of the host ring
+constexpr int kCopyStreams = 4;
+constexpr int kMaxTake = 16;                                       // images one coder thread codes together (two AVX-512 packs)
 
 struct ReadyImage {                                                  // everything a coder thread needs
-    int hb, job, h, w;
+    int cb, job, h, w;
     uint32_t n_ev;
     unsigned char *const *outs; const size_t *caps; long *lens;      // -e1: byte streams; effort 0: uint16_t streams, caps/lens in words
     int kind;                                                        // 0 = NBLIC -e1 range coder, 1 = QNBLIC entropy stage
@@ -94,7 +112,7 @@ struct Slot {
     E1Buffers b{};
     size_t px_cap = 0, ev_cap = 0, img_cap = 0;
     uint8_t *d_img = nullptr;         // device copy when the caller hands a host image
-    int hb = -1;                      // pinned host buffer that receives this image's coded bins
+    int cb = -1;                      // coded-bin buffer (HBM) this image's back half writes to
     int job = -1, h = 0, w = 0;       // current image
     uint32_t n_ev = 0;
 };
@@ -114,6 +132,8 @@ struct Group {
     // the batch this group currently serves (valid from launch_back until its coders finish)
     unsigned char *const *outs = nullptr; const size_t *caps = nullptr; long *lens = nullptr;
     int kind = 0;
+    // hand-over to the group's driver thread (guarded by ctx->dm)
+    const uint8_t *const *imgs = nullptr; bool on_device = false; bool has_work = false;
 };
 
 template <class T> static bool dev_alloc(T *&p, size_t count) {
@@ -137,8 +157,9 @@ struct nblic_amd_ctx {
     std::mutex fm;                        // free groups / free host buffers / outstanding work
     std::condition_variable fcv;
     std::deque<int> free_groups;
-    std::vector<HostBuf> hbufs;
-    std::deque<int> free_hbufs;
+    std::vector<hipStream_t> copy_streams;   // shared by the coder threads (device -> host chunk copies)
+    std::vector<CodedBuf> cbufs;
+    std::deque<int> free_cbufs;
     int coding = 0;                       // images handed to the GPU whose streams are not finished yet
     // coder threads
     std::vector<std::thread> coders;
@@ -148,10 +169,20 @@ struct nblic_amd_ctx {
     int idle_coders = 0;
     int batch_to_come = 0;                // images of the running batch that have not reached `ready` yet (guarded by rm)
     bool stop = false;
+    // One driver thread per group: a group's launch sequence has a host round trip in the middle
+    // (the event count sizes the back half) and may wait for a pinned buffer; with a thread each,
+    // one group waiting never keeps the others from being launched.
+    std::vector<std::thread> drivers;
+    std::mutex dm;
+    std::condition_variable dcv;
+    bool stop_drivers = false;
+    std::atomic<bool> failed{false};
     // reporting
     double stage_ms[kE1Kernels] = {0};
     long stage_launches = 0;
     double total_bins = 0, coder_s = 0;
+    double pack_bins = 0, pack_s = 0;     // the part of the above coded eight at a time
+    double wait_s = 0;                    // of coder_s: waiting for bins to arrive from HBM
     std::mutex stat_m;
     SerialEngine serial;
 };
@@ -162,7 +193,7 @@ static bool group_init(Group &g, int id, int n_slots, nblic_amd_ctx *c) {
     g.id = id; g.ctx = c;
     g.slots.resize(size_t(n_slots));
     HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming | hipEventBlockingSync));
     for (auto &e : g.tm.ev) HIP_OK(hipEventCreate(&e));
     HIP_OK(hipHostMalloc((void **)&g.h_jobs, size_t(n_slots) * sizeof(E1Job), hipHostMallocDefault));
     HIP_OK(hipMalloc((void **)&g.d_jobs, size_t(n_slots) * sizeof(E1Job)));
@@ -177,7 +208,7 @@ static bool group_init(Group &g, int id, int n_slots, nblic_amd_ctx *c) {
         HIP_OK(hipMalloc((void **)&s.b.qhist, 12 * 256 * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.map_state, 512 * 60 * sizeof(int)));
         HIP_OK(hipMalloc((void **)&s.b.cnt_state, 4096 * 2 * sizeof(int)));
-        HIP_OK(hipMalloc((void **)&s.b.win_base, 4097 * sizeof(uint32_t)));
+        HIP_OK(hipMalloc((void **)&s.b.win_base, (4097 + 4096) * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.blk_base, 4097 * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.dbg_out, 4096 * sizeof(unsigned long long)));
         HIP_OK(hipMemset(s.b.dbg_out, 0, 4096 * sizeof(unsigned long long)));
@@ -190,7 +221,7 @@ static void group_free(Group &g) {
         hipFree(s.b.rec1); hipFree(s.b.s2in); hipFree(s.b.pos2); hipFree(s.b.s2out); hipFree(s.b.pxs); hipFree(s.b.s3in);
         hipFree(s.b.pos3); hipFree(s.b.s3out); hipFree(s.b.z); hipFree(s.b.cnt); hipFree(s.b.ev_off); hipFree(s.b.table);
         hipFree(s.b.scan_sums); hipFree(s.b.ctx_state); hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events);
-        hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.coded); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.dbg_out); hipFree(s.b.qhist); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
+        hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.dbg_out); hipFree(s.b.qhist); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
     }
     hipFree(g.d_jobs); hipFree(g.d_totals);
     if (g.h_jobs) hipHostFree(g.h_jobs);
@@ -204,7 +235,7 @@ static bool ensure_events(Slot &s, size_t n_ev) {
     if (n_ev <= s.ev_cap) return true;
     size_t cap = n_ev + n_ev / 8 + 1024;
     if (!dev_alloc(s.b.events, cap) || !dev_alloc(s.b.tin, 2 * cap + kStreamPad) || !dev_alloc(s.b.tpos, cap) ||
-        !dev_alloc(s.b.tout, 2 * cap + kStreamPad) || !dev_alloc(s.b.coded, cap) ||
+        !dev_alloc(s.b.tout, 2 * cap + kStreamPad) ||
         !dev_alloc(s.b.win_recs, (2 * cap / 512 + 4096 + 8) * 24)) return false;
     s.ev_cap = cap;
     return true;
@@ -246,27 +277,100 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
     return true;
 }
 
-// Coder thread.  Measured on the GPU box (EPYC 9575F): one stream alone codes 500 Mbins/s, eight
-// streams in the lanes of one AVX-512 register 1060 Mbins/s together -- twice the throughput of
-// the thread, at 3.8x the latency of each stream.  So a thread takes a single image while there
-// are enough idle threads to go round (shortest latency, right for a short batch and for its
-// tail) and a pack of eight only when work is piling up.
-static void coder_main(nblic_amd_ctx *c) {
+// What a coder thread owns: a pinned ring of two half-buffers x sixteen lanes x kChunkBins, so chunk
+// c+1 lands while chunk c is coded.  Its device->host copies go through one of the context's few
+// copy streams: a stream per thread would outnumber the hardware queues, and streams that share a
+// hardware queue with a group's kernels have their copies stuck behind those kernels.
+struct CoderThread {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    uint16_t *ring = nullptr;
+    uint16_t *whole = nullptr; size_t whole_cap = 0;     // pinned; one whole QNBLIC image (its rANS runs last pixel first)
+    RangeX8 x8, x8b;
+    RangeScalar x1;
+    double wait_s = 0;                                   // time spent waiting for chunks (reporting)
+    bool init(int device, hipStream_t copy_stream) {
+        HIP_OK(hipSetDevice(device));
+        stream = copy_stream;
+        for (auto &e : ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
+        return true;
+    }
+    void destroy() {
+        if (ring) hipHostFree(ring);
+        if (whole) hipHostFree(whole);
+        for (auto &e : ev) if (e) hipEventDestroy(e);
+    }
+    uint16_t *slot(int half, int lane) { return ring + (size_t(half) * kMaxTake + size_t(lane)) * kChunkBins; }
+};
+
+// Streams `take` images' bins from HBM and codes them: one image with the scalar coder, up to
+// eight in the lanes of the AVX-512 coder, up to sixteen as two packs in lock-step.
+// lens[k] = coder bytes or SIZE_MAX.
+static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size_t *n, int take, uint8_t *const *dst,
+                          const size_t *caps, size_t *lens) {
+    if (!t.ring) HIP_OK(hipHostMalloc((void **)&t.ring, 2 * kMaxTake * kChunkBins * sizeof(uint16_t), hipHostMallocDefault));
+    size_t n_max = 0;
+    for (int k = 0; k < take; k++) n_max = n[k] > n_max ? n[k] : n_max;
+    const size_t chunks = (n_max + kChunkBins - 1) / kChunkBins;
+    auto chunk_len = [&](size_t c, int k) { const size_t off = c * kChunkBins; return off >= n[k] ? size_t(0) : (n[k] - off < kChunkBins ? n[k] - off : kChunkBins); };
+    auto issue = [&](size_t c) -> bool {
+        for (int k = 0; k < take; k++)
+            if (size_t len = chunk_len(c, k))
+                HIP_OK(hipMemcpyAsync(t.slot(int(c & 1), k), dev[k] + c * kChunkBins, len * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
+        HIP_OK(hipEventRecord(t.ev[c & 1], t.stream));
+        return true;
+    };
+    if (take > 8) { t.x8.begin(8, dst, caps); t.x8b.begin(take - 8, dst + 8, caps + 8); }
+    else if (take > 1) t.x8.begin(take, dst, caps);
+    else t.x1.begin(dst[0], caps[0]);
+    if (chunks && !issue(0)) return false;
+    for (size_t c = 0; c < chunks; c++) {
+        if (c + 1 < chunks && !issue(c + 1)) return false;
+        auto w0 = std::chrono::steady_clock::now();
+        HIP_OK(hipEventSynchronize(t.ev[c & 1]));
+        t.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+        const uint16_t *src[kMaxTake]; size_t len[kMaxTake];
+        for (int k = 0; k < kMaxTake; k++) { src[k] = t.slot(int(c & 1), k); len[k] = k < take ? chunk_len(c, k) : 0; }
+        if (take > 8) feed_pair(t.x8, src, len, t.x8b, src + 8, len + 8);
+        else if (take > 1) t.x8.feed(src, len);
+        else t.x1.feed(src[0], len[0]);
+    }
+    if (take > 8) { t.x8.end(lens); t.x8b.end(lens + 8); }
+    else if (take > 1) t.x8.end(lens);
+    else lens[0] = t.x1.finish();
+    return true;
+}
+
+// Coder thread.  Measured on the GPU box (EPYC 9575F), per thread: one stream alone 440-510
+// Mbins/s, eight streams in the lanes of one AVX-512 register 1095 Mbins/s together, two such
+// packs in lock-step 1460 Mbins/s -- at 3x / 4.6x the latency of a stream coded alone.  The
+// host's CPU share, not the GPU, bounds the pipeline, so under load the threads must work in
+// packs; but a short batch, and the tail of a long one, finish sooner as singles spread over the
+// threads.  Policy (picked with a discrete-event model of arrivals and coder speeds, tools/
+// coder_policy_sim.py): a single while any other thread is idle, a pack of eight when this is the
+// only idle thread and plenty of work is left, sixteen when there is plenty queued as well.
+static int coder_take(const nblic_amd_ctx *c) {                  // call with c->rm held; 0 = nothing to take
+    const size_t q = c->ready.size();
+    if (q == 0) return 0;
+    if (c->ready.front().kind != 0 || !c->simd) return 1;
+    const size_t left = q + size_t(c->batch_to_come), threads = c->coders.size();
+    if (q >= 8 && c->idle_coders == 1 && left >= 3 * threads) return (q >= size_t(kMaxTake) && left >= 8 * threads) ? kMaxTake : 8;
+    return 1;
+}
+
+static void coder_main(nblic_amd_ctx *c, int index) {
+    CoderThread t;
+    if (!t.init(c->device, c->copy_streams[size_t(index) % c->copy_streams.size()])) c->failed = true;
     for (;;) {
-        ReadyImage im[8];
+        ReadyImage im[kMaxTake];
         int take = 0;
         {
             std::unique_lock<std::mutex> l(c->rm);
             c->idle_coders++;
             c->rcv.wait(l, [c] { return c->stop || !c->ready.empty(); });
-            if (c->ready.empty()) return;
-            // A pack pays only when every other thread is busy and plenty of work is left: eight
-            // streams take 3.8x as long as one, so a short batch (or the tail of a long one) finishes
-            // sooner as singles spread over the threads (policy picked with a discrete-event model).
-            const size_t q = c->ready.size(), left = q + size_t(c->batch_to_come);
-            take = (c->simd && q >= 8 && c->idle_coders == 1 && left >= 3 * c->coders.size()) ? 8 : 1;
+            if (c->ready.empty()) break;
+            take = coder_take(c);
             c->idle_coders--;
-            if (c->ready.front().kind != 0) take = 1;
             for (int k = 0; k < take; k++) {
                 if (k > 0 && c->ready.front().kind != 0) { take = k; break; }
                 im[k] = c->ready.front(); c->ready.pop_front();
@@ -274,53 +378,91 @@ static void coder_main(nblic_amd_ctx *c) {
         }
         if (im[0].kind == 1) {                               // QNBLIC: histogram normalisation + rANS, one image per thread
             const ReadyImage &q = im[0];
-            const uint16_t *qy = c->hbufs[size_t(q.hb)].p;
-            const uint32_t *hist = reinterpret_cast<const uint32_t *>(qy + ((size_t(q.h) * size_t(q.w) + 1) & ~size_t(1)));
-            auto *out = reinterpret_cast<uint16_t *>(q.outs[q.job]);
-            long words = q_entropy_encode(out, q.caps[q.job], q.h, q.w, qy, hist);
-            if (words < 0) fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu words is too small\n", q.job, q.caps[q.job]);
-            q.lens[q.job] = words;
-            { std::lock_guard<std::mutex> l(c->fm); c->free_hbufs.push_back(q.hb); c->coding -= 1; }
+            const size_t n = size_t(q.h) * size_t(q.w), n_pad = (n + 1) & ~size_t(1), words = n_pad + 2 * 12 * 256;
+            bool ok = true;
+            if (t.whole_cap < words) {
+                if (t.whole) hipHostFree(t.whole);
+                t.whole = nullptr; t.whole_cap = 0;
+                if (hipHostMalloc((void **)&t.whole, (words + 1024) * sizeof(uint16_t), hipHostMallocDefault) == hipSuccess) t.whole_cap = words + 1024;
+                else ok = false;
+            }
+            ok = ok && hipMemcpyAsync(t.whole, c->cbufs[size_t(q.cb)].p, words * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream) == hipSuccess &&
+                 hipEventRecord(t.ev[0], t.stream) == hipSuccess && hipEventSynchronize(t.ev[0]) == hipSuccess;
+            long words_out = -1;
+            if (ok) {
+                const uint32_t *hist = reinterpret_cast<const uint32_t *>(t.whole + n_pad);
+                words_out = q_entropy_encode(reinterpret_cast<uint16_t *>(q.outs[q.job]), q.caps[q.job], q.h, q.w, t.whole, hist);
+                if (words_out < 0) fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu words is too small\n", q.job, q.caps[q.job]);
+            } else {
+                c->failed = true;
+            }
+            q.lens[q.job] = words_out;
+            { std::lock_guard<std::mutex> l(c->fm); c->free_cbufs.push_back(q.cb); c->coding -= 1; }
             c->fcv.notify_all();
             continue;
         }
         auto t0 = std::chrono::steady_clock::now();
-        const uint16_t *src[8]; size_t n[8], caps[8], lens[8]; uint8_t *dst[8];
+        const uint16_t *src[kMaxTake]; size_t n[kMaxTake], caps[kMaxTake], lens[kMaxTake]; uint8_t *dst[kMaxTake];
         double bins = 0;
         for (int k = 0; k < take; k++) {
-            src[k] = c->hbufs[size_t(im[k].hb)].p; n[k] = im[k].n_ev; bins += double(im[k].n_ev);
-            const size_t cap = im[k].caps[im[k].job];
+            src[k] = c->cbufs[size_t(im[k].cb)].p; n[k] = im[k].n_ev; bins += double(im[k].n_ev);
+            const size_t cap = im[k].caps[im[k].job] < (size_t(1) << 46) ? im[k].caps[im[k].job] : (size_t(1) << 46);   // SIZE_MAX = "no limit"
             dst[k] = im[k].outs[im[k].job] + kHeaderBytes;
             caps[k] = cap >= size_t(kHeaderBytes) ? cap - kHeaderBytes : 0;
             if (cap >= size_t(kHeaderBytes)) write_header(im[k].outs[im[k].job], im[k].h, im[k].w, 0, kMinKStep, 1);
         }
-        if (take > 1) range_code_x8(src, n, take, dst, caps, lens);
-        else lens[0] = range_code(src[0], n[0], dst[0], caps[0]);
+        static const bool skip_coding = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 16);   // measurement aid: device side alone
+        if (skip_coding) { for (int k = 0; k < take; k++) lens[k] = 0; }
+        else if (!code_streamed(t, src, n, take, dst, caps, lens)) {
+            c->failed = true;
+            hipDeviceSynchronize();
+            for (int k = 0; k < take; k++) lens[k] = SIZE_MAX;
+        }
         for (int k = 0; k < take; k++) {
             if (lens[k] == SIZE_MAX) fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", im[k].job, im[k].caps[im[k].job]);
             im[k].lens[im[k].job] = lens[k] == SIZE_MAX ? -1 : long(kHeaderBytes + lens[k]);
         }
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; }
+        { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; if (take > 1) { c->pack_bins += bins; c->pack_s += dt; } c->wait_s += t.wait_s; t.wait_s = 0; }
         {
             std::lock_guard<std::mutex> l(c->fm);
-            for (int k = 0; k < take; k++) c->free_hbufs.push_back(im[k].hb);
+            for (int k = 0; k < take; k++) c->free_cbufs.push_back(im[k].cb);
             c->coding -= take;
         }
         c->fcv.notify_all();
     }
+    t.destroy();
 }
 
-// Runs on a HIP runtime thread when the group's device->host copies have landed: queues the
-// images for the coder threads and hands the device workspace back.  (No HIP calls in here.)
-static void on_group_copied(void *vp) {
+// Takes a coded-bin buffer of at least `words` for slot s (waits for one if the coder threads are
+// behind: that is the pipeline's back-pressure).
+static bool acquire_coded(nblic_amd_ctx *c, Slot &s, size_t words) {
+    {
+        std::unique_lock<std::mutex> l(c->fm);
+        c->fcv.wait(l, [c] { return !c->free_cbufs.empty(); });
+        s.cb = c->free_cbufs.front(); c->free_cbufs.pop_front();
+    }
+    CodedBuf &cb = c->cbufs[size_t(s.cb)];
+    if (cb.cap < words) {
+        if (cb.p) hipFree(cb.p);
+        cb.p = nullptr; cb.cap = 0;
+        const size_t cap = words + words / 8 + 1024;
+        HIP_OK(hipMalloc((void **)&cb.p, cap * sizeof(uint16_t)));
+        cb.cap = cap;
+    }
+    return true;
+}
+
+// Runs on a HIP runtime thread when the group's kernels have finished: queues the images for the
+// coder threads and hands the device workspace back.  (No HIP calls in here.)
+static void on_group_done(void *vp) {
     Group *gp = static_cast<Group *>(vp);
     nblic_amd_ctx *c = gp->ctx;
     {
         std::lock_guard<std::mutex> l(c->rm);
         for (int k = 0; k < gp->n_jobs; k++) {
             const Slot &s = gp->slots[size_t(k)];
-            c->ready.push_back(ReadyImage{s.hb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens, gp->kind});
+            c->ready.push_back(ReadyImage{s.cb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens, gp->kind});
         }
         c->batch_to_come -= gp->n_jobs;
     }
@@ -330,39 +472,24 @@ static void on_group_copied(void *vp) {
 }
 
 static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders) {
-    HIP_OK(hipStreamSynchronize(g.stream));
+    // a BLOCKING wait: a spinning one per driver thread would take cores from the coder threads
+    HIP_OK(hipEventRecord(g.done, g.stream));
+    HIP_OK(hipEventSynchronize(g.done));
     for (int k = 0; k < g.n_jobs; k++) {
         Slot &s = g.slots[size_t(k)];
         s.n_ev = g.h_totals[size_t(k) * 4 + 2];
         if (s.n_ev >= 0x7FFFFFFFu) { fprintf(stderr, "[nblic_amd] event count overflow\n"); return false; }
         if (!ensure_events(s, s.n_ev)) return false;
+        // the coded bins go straight into a pool buffer that outlives this group's turn on the slot
+        if (!acquire_coded(c, s, size_t(s.n_ev) + 8)) return false;
+        s.b.coded = c->cbufs[size_t(s.cb)].p;
         E1Job &J = g.h_jobs[k];
         J.b = s.b; J.n_ev = s.n_ev; J.pe = make_plan(s.n_ev, kTouchSegments);
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
     e1_launch_back(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);
     g.tm_pending = c->timing;
-    for (int k = 0; k < g.n_jobs; k++) {
-        Slot &s = g.slots[size_t(k)];
-        {   // a pinned host buffer for the coded bins; they outnumber the device slots, so the GPU
-            // can move on to the next images while these wait for a coder thread
-            std::unique_lock<std::mutex> l(c->fm);
-            c->fcv.wait(l, [c] { return !c->free_hbufs.empty(); });
-            s.hb = c->free_hbufs.front(); c->free_hbufs.pop_front();
-        }
-        HostBuf &hb = c->hbufs[size_t(s.hb)];
-        if (hb.cap < size_t(s.n_ev) + 8) {
-            if (hb.p) hipHostFree(hb.p);
-            hb.p = nullptr;
-            hb.cap = size_t(s.n_ev) + size_t(s.n_ev) / 8 + 1024;
-            HIP_OK(hipHostMalloc((void **)&hb.p, hb.cap * sizeof(uint16_t), hipHostMallocDefault));
-        }
-        HIP_OK(hipMemcpyAsync(hb.p, s.b.coded, size_t(s.n_ev) * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
-    }
-    if (with_coders) {
-        { std::lock_guard<std::mutex> l(c->fm); c->coding += g.n_jobs; }
-        HIP_OK(hipLaunchHostFunc(g.stream, on_group_copied, &g));
-    }
+    if (with_coders) HIP_OK(hipLaunchHostFunc(g.stream, on_group_done, &g));       // the caller has counted the images in ctx->coding
     return true;
 }
 
@@ -382,15 +509,49 @@ static void release_group(nblic_amd_ctx *c, int id) {
     c->fcv.notify_all();
 }
 
-// Groups are started one after the other: front half of group g+1 overlaps the back half of
-// group g on the GPU, and the host codes group g while the GPU is busy with g+1, g+2, ...
+static bool launch_q(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, bool on_device);
+
+static void driver_main(nblic_amd_ctx *c, int id) {
+    Group &g = c->groups[size_t(id)];
+    if (hipSetDevice(c->device) != hipSuccess) fprintf(stderr, "[nblic_amd] driver thread: cannot select device %d\n", c->device);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> l(c->dm);
+            c->dcv.wait(l, [&] { return c->stop_drivers || g.has_work; });
+            if (!g.has_work) return;
+            g.has_work = false;
+        }
+        const bool ok = g.kind == 0 ? (launch_front(c, g, g.imgs, g.on_device) && launch_back(c, g, true))
+                                    : launch_q(c, g, g.imgs, g.on_device);
+        if (!ok) {
+            c->failed = true;
+            hipStreamSynchronize(g.stream);
+            { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come -= g.n_jobs; }
+            c->rcv.notify_all();                                 // a pack may be waiting for images that will not come
+            { std::lock_guard<std::mutex> l(c->fm); c->coding -= g.n_jobs; }
+            release_group(c, id);
+        }
+    }
+}
+
+// The images are counted as outstanding BEFORE the driver thread is woken, so the batch's final
+// wait cannot slip through between the hand-over and the launch.
+static void start_group(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, bool on_device) {
+    { std::lock_guard<std::mutex> l(c->fm); c->coding += g.n_jobs; }
+    { std::lock_guard<std::mutex> l(c->dm); g.imgs = imgs; g.on_device = on_device; g.has_work = true; }
+    c->dcv.notify_all();
+}
+
+// Groups are started one after the other and run concurrently on the GPU (a stream each); the
+// host codes finished groups while the GPU is busy with the following ones.
 static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *imgs, bool on_device, const int *hs,
                          const int *ws, uint8_t *const *outs, const size_t *caps, long *lens) {
     if (hipSetDevice(c->device) != hipSuccess) return false;
     for (auto &v : c->stage_ms) v = 0;
     c->stage_launches = 0;
-    c->total_bins = 0; c->coder_s = 0;
+    c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0;
     bool ok = true;
+    c->failed = false;
     for (int k = 0; k < n_images; k++) lens[k] = -1;
     { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come = n_images; }
     int next = 0;
@@ -412,20 +573,20 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
             s.job = k; s.h = hs[k]; s.w = ws[k];
         }
         if (g.n_jobs == 0) { release_group(c, id); continue; }
-        if (!launch_front(c, g, imgs, on_device) || !launch_back(c, g, true)) {
-            ok = false;
-            hipStreamSynchronize(g.stream);
-            { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come -= g.n_jobs; }
-            release_group(c, id);
-        }
+        start_group(c, g, imgs, on_device);
     }
     {   // wait for the coder threads (and with them every group's GPU work)
         std::unique_lock<std::mutex> l(c->fm);
         c->fcv.wait(l, [c] { return c->coding == 0; });
     }
     for (auto &g : c->groups) collect_timing(c, g);
+    if (getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 32))
+        fprintf(stderr, "[nblic_amd] coder: singles %.0f Mbins in %.2f thread-s (%.0f Mbins/s), packs %.0f Mbins in %.2f thread-s (%.0f Mbins/s)\n",
+                (c->total_bins - c->pack_bins) / 1e6, c->coder_s - c->pack_s, (c->total_bins - c->pack_bins) / 1e6 / (c->coder_s - c->pack_s + 1e-9),
+                c->pack_bins / 1e6, c->pack_s, c->pack_bins / 1e6 / (c->pack_s + 1e-9)),
+        fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that waiting for chunks\n", c->wait_s);
     for (int k = 0; k < n_images; k++) if (lens[k] < 0) ok = false;
-    return ok;
+    return ok && !c->failed;
 }
 
 // ---- QNBLIC (effort 0): model on the GPU, entropy stage on a coder thread ---------------------
@@ -451,22 +612,12 @@ static bool launch_q(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, boo
     for (int k = 0; k < g.n_jobs; k++) {
         Slot &s = g.slots[size_t(k)];
         const size_t n = size_t(s.h) * size_t(s.w), n_pad = (n + 1) & ~size_t(1), need = n_pad + 2 * 12 * 256;
-        {
-            std::unique_lock<std::mutex> l(c->fm);
-            c->fcv.wait(l, [c] { return !c->free_hbufs.empty(); });
-            s.hb = c->free_hbufs.front(); c->free_hbufs.pop_front();
-        }
-        HostBuf &hb = c->hbufs[size_t(s.hb)];
-        if (hb.cap < need) {
-            if (hb.p) hipHostFree(hb.p);
-            hb.p = nullptr; hb.cap = need + 1024;
-            HIP_OK(hipHostMalloc((void **)&hb.p, hb.cap * sizeof(uint16_t), hipHostMallocDefault));
-        }
-        HIP_OK(hipMemcpyAsync(hb.p, s.b.pxs, n * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
-        HIP_OK(hipMemcpyAsync(hb.p + n_pad, s.b.qhist, 12 * 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+        if (!acquire_coded(c, s, need)) return false;
+        uint16_t *dst = c->cbufs[size_t(s.cb)].p;
+        HIP_OK(hipMemcpyAsync(dst, s.b.pxs, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, g.stream));
+        HIP_OK(hipMemcpyAsync(dst + n_pad, s.b.qhist, 12 * 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));
     }
-    { std::lock_guard<std::mutex> l(c->fm); c->coding += g.n_jobs; }
-    HIP_OK(hipLaunchHostFunc(g.stream, on_group_copied, &g));
+    HIP_OK(hipLaunchHostFunc(g.stream, on_group_done, &g));
     return true;
 }
 
@@ -474,6 +625,7 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
                            const int *ws, uint16_t *const *outs, const size_t *caps_words, long *len_words) {
     if (hipSetDevice(c->device) != hipSuccess) return false;
     bool ok = true;
+    c->failed = false;
     for (int k = 0; k < n_images; k++) len_words[k] = -1;
     { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come = n_images; }
     int next = 0;
@@ -495,19 +647,14 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
             s.job = k; s.h = hs[k]; s.w = ws[k];
         }
         if (g.n_jobs == 0) { release_group(c, id); continue; }
-        if (!launch_q(c, g, imgs, on_device)) {
-            ok = false;
-            hipStreamSynchronize(g.stream);
-            { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come -= g.n_jobs; }
-            release_group(c, id);
-        }
+        start_group(c, g, imgs, on_device);
     }
     {
         std::unique_lock<std::mutex> l(c->fm);
         c->fcv.wait(l, [c] { return c->coding == 0; });
     }
     for (int k = 0; k < n_images; k++) if (len_words[k] < 0) ok = false;
-    return ok;
+    return ok && !c->failed;
 }
 
 // ---- default context behind the drop-in entry points ---------------------------------------
@@ -538,7 +685,7 @@ int nblic_amd_range_code_multi(const uint16_t *const *coded, const size_t *n, in
                                const size_t *caps, size_t *lens) {
     if (count < 0) return -1;
     if (have_avx512()) {
-        for (int k = 0; k < count; k += 8) range_code_x8(coded + k, n + k, count - k < 8 ? count - k : 8, outs + k, caps + k, lens + k);
+        for (int k = 0; k < count; k += 16) range_code_x8(coded + k, n + k, count - k < 16 ? count - k : 16, outs + k, caps + k, lens + k);
         return 1;
     }
     for (int k = 0; k < count; k++) lens[k] = range_code(coded[k], n[k], outs[k], caps[k]);
@@ -577,7 +724,7 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     if (n_groups < 1) n_groups = 1;
     if (group_size < 1) group_size = 1;
     if (n_coders < 1) n_coders = 1;
-    if (n_host_buffers < n_groups * group_size) n_host_buffers = n_groups * group_size;
+    if (n_host_buffers < n_groups * group_size + kMaxTake) n_host_buffers = n_groups * group_size + kMaxTake;   // groups in flight + one pack filling
     auto *c = new nblic_amd_ctx;
     c->device = device;
     c->simd = have_avx512() && !getenv("NBLIC_AMD_NO_SIMD");
@@ -586,10 +733,14 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
         if (!group_init(c->groups[size_t(i)], i, group_size, c)) { nblic_amd_destroy(c); return nullptr; }
         c->free_groups.push_back(i);
     }
-    c->hbufs.resize(size_t(n_host_buffers));
-    for (int i = 0; i < n_host_buffers; i++) c->free_hbufs.push_back(i);
+    c->cbufs.resize(size_t(n_host_buffers));
+    for (int i = 0; i < n_host_buffers; i++) c->free_cbufs.push_back(i);
     if (!c->serial.init()) { nblic_amd_destroy(c); return nullptr; }
-    for (int i = 0; i < n_coders; i++) c->coders.emplace_back(coder_main, c);
+    c->copy_streams.resize(size_t(n_coders < kCopyStreams ? n_coders : kCopyStreams));
+    for (auto &cs : c->copy_streams)
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { cs = nullptr; nblic_amd_destroy(c); return nullptr; }
+    for (int i = 0; i < n_coders; i++) c->coders.emplace_back(coder_main, c, i);
+    for (int i = 0; i < n_groups; i++) c->drivers.emplace_back(driver_main, c, i);
     return c;
 }
 
@@ -607,8 +758,12 @@ void nblic_amd_destroy(nblic_amd_ctx *c) {
     { std::lock_guard<std::mutex> l(c->rm); c->stop = true; }
     c->rcv.notify_all();
     for (auto &t : c->coders) t.join();
+    { std::lock_guard<std::mutex> l(c->dm); c->stop_drivers = true; }
+    c->dcv.notify_all();
+    for (auto &t : c->drivers) t.join();
     for (auto &g : c->groups) group_free(g);
-    for (auto &hb : c->hbufs) if (hb.p) hipHostFree(hb.p);
+    for (auto &cb : c->cbufs) if (cb.p) hipFree(cb.p);
+    for (auto &cs : c->copy_streams) if (cs) hipStreamDestroy(cs);
     c->serial.destroy();
     delete c;
 }
@@ -645,7 +800,7 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
     { std::unique_lock<std::mutex> l(c->fm); c->fcv.wait(l, [c] { return !c->free_groups.empty(); }); id = c->free_groups.front(); c->free_groups.pop_front(); }
     Group &grp = c->groups[size_t(id)];
     Slot &s = grp.slots[0];
-    grp.n_jobs = 1; s.job = 0; s.h = h; s.w = w;
+    grp.n_jobs = 1; s.job = 0; s.h = h; s.w = w; s.cb = -1;
     const uint8_t *imgs[1] = {img};
     long count = -1;
     size_t n = size_t(h) * size_t(w);
@@ -664,7 +819,7 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
         }
         if (src && cnt * esz <= out_bytes && hipMemcpy(out, src, cnt * esz, hipMemcpyDeviceToHost) == hipSuccess) count = long(cnt);
     }
-    if (s.hb >= 0) { std::lock_guard<std::mutex> l(c->fm); c->free_hbufs.push_back(s.hb); s.hb = -1; }
+    if (s.cb >= 0) { std::lock_guard<std::mutex> l(c->fm); c->free_cbufs.push_back(s.cb); s.cb = -1; }
     release_group(c, id);
     return count;
 }

@@ -1,0 +1,43 @@
+// range_coder.h -- host side of stage S6: the 32-bit carry-less binary range coder (NBLIC.c:527-586)
+// in resumable form.  The coder threads stream an image's bins from HBM chunk by chunk, so both
+// coders keep their state between calls: begin() once, feed() per chunk, end() once.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nblic {
+
+// One stream.  coded[r] = prob (12 bit, P(bin==1)) | bin << 15.  Bin 1 takes the lower part of [lo, hi].
+struct RangeScalar {
+    uint32_t lo = 0, hi = 0xFFFFFFFFu;
+    uint8_t *out = nullptr, *p = nullptr, *end = nullptr;
+    bool overflow = false;
+    void begin(uint8_t *out_, size_t cap) {
+        lo = 0; hi = 0xFFFFFFFFu; out = p = out_; overflow = cap < 4;
+        end = out_ + (cap < 4 ? 0 : cap - 4);                  // keep room for the flush
+    }
+    void feed(const uint16_t *coded, size_t n);
+    size_t finish();                                           // bytes written, or SIZE_MAX if the output did not fit
+};
+
+// Eight streams in the eight 64-bit lanes of one AVX-512 register (range_coder_x8.cpp).
+struct RangeX8 {
+    struct State;
+    State *st;
+    RangeX8();
+    ~RangeX8();
+    RangeX8(const RangeX8 &) = delete;
+    RangeX8 &operator=(const RangeX8 &) = delete;
+    void begin(int count, uint8_t *const *outs, const size_t *caps);
+    void feed(const uint16_t *const *src, const size_t *len);  // lane k codes src[k][0 .. len[k]); len 0 = idle
+    void end(size_t *lens);                                    // per lane: bytes written or SIZE_MAX
+};
+
+// two packs (sixteen streams) advanced in lock-step by one thread
+void feed_pair(RangeX8 &a, const uint16_t *const *src_a, const size_t *len_a, RangeX8 &b, const uint16_t *const *src_b, const size_t *len_b);
+
+bool have_avx512();
+size_t range_code(const uint16_t *coded, size_t n, uint8_t *out, size_t cap);
+void range_code_x8(const uint16_t *const *coded, const size_t *n, int count, uint8_t *const *outs, const size_t *caps, size_t *lens);
+
+}  // namespace nblic

@@ -12,6 +12,10 @@
 #include <immintrin.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <new>
+
+#include "range_coder.h"
 
 namespace nblic {
 
@@ -85,65 +89,140 @@ NB_TARGET inline void step(Lanes &L, __m512i ev, __mmask8 kact) {
 
 }  // namespace
 
-// Codes `count` (<= 8) streams.  coded[k][0..n[k]) are u16 bins (prob | bin << 15); outs[k] has
-// caps[k] bytes.  lens[k] = bytes written (coder bytes + 4 flush bytes) or SIZE_MAX if it did not fit.
-NB_TARGET void range_code_x8(const uint16_t *const *coded, const size_t *n, int count, uint8_t *const *outs,
-                             const size_t *caps, size_t *lens) {
-    if (count <= 0) return;
-    Lanes L;
-    alignas(64) uint64_t base[8], nn[8];
-    size_t nmin = SIZE_MAX, nmax = 0;
+// Resumable form: the coder threads stream each image's bins from HBM in chunks, so the eight
+// lanes are fed piecewise.  begin() once, feed() per chunk, end() once.
+struct RangeX8::State { Lanes L; uint8_t *out0[8]; int count; };
+
+RangeX8::RangeX8() : st(nullptr) {}
+RangeX8::~RangeX8() { if (st) { st->~State(); free(st); } }
+
+NB_TARGET void RangeX8::begin(int count, uint8_t *const *outs, const size_t *caps) {
+    if (!st) { st = (State *)aligned_alloc(64, (sizeof(State) + 63) & ~size_t(63)); new (st) State; }
+    Lanes &L = st->L;
+    st->count = count;
     for (int k = 0; k < 8; k++) {
-        const int s = k < count ? k : 0;                     // idle lanes read lane 0's (valid) memory, never update
-        base[k] = (uint64_t)(uintptr_t)coded[s];
-        nn[k] = k < count ? n[k] : 0;
         L.outp[k] = k < count ? outs[k] : nullptr;
         L.oend[k] = k < count ? outs[k] + caps[k] : nullptr;
         L.overflow[k] = false;
-        if (k < count) { if (n[k] < nmin) nmin = n[k]; if (n[k] > nmax) nmax = n[k]; }
+        st->out0[k] = L.outp[k];
     }
     L.lo = _mm512_setzero_si512();
     L.span = _mm512_set1_epi64(0xFFFFFFFFll);
     L.acc = _mm512_setzero_si512();
     L.cnt = _mm512_setzero_si512();
+}
+
+// Lane k codes src[k][0 .. len[k]) (len 0 = lane idle in this chunk).  While every active lane has
+// four bins left, one 8-byte gather per lane brings the next four bins of every stream; lanes drop
+// out of the mask as their chunk ends.
+NB_TARGET void RangeX8::feed(const uint16_t *const *src, const size_t *len) {
+    Lanes &L = st->L;
+    const int count = st->count;
+    alignas(64) uint64_t base[8];
+    for (int k = 0; k < 8; k++) base[k] = (k < count && len[k]) ? (uint64_t)(uintptr_t)src[k] : 0;
     const __m512i vbase = _mm512_load_si512((const void *)base);
-    const __mmask8 kall = (__mmask8)((1u << count) - 1u);
-    size_t r = 0;
-    // all streams alive: one 8-byte gather per lane brings the next four bins of every stream
-    for (; r + 4 <= nmin; r += 4) {
-        const __m512i addr = _mm512_add_epi64(vbase, _mm512_set1_epi64((long long)(2 * r)));
-        const __m512i g = _mm512_i64gather_epi64(addr, (const void *)0, 1);
-        step(L, g, kall);
-        step(L, _mm512_srli_epi64(g, 16), kall);
-        step(L, _mm512_srli_epi64(g, 32), kall);
-        step(L, _mm512_srli_epi64(g, 48), kall);
-    }
-    // ragged tail: lanes drop out as their stream ends
-    for (; r < nmax; r++) {
-        alignas(64) uint64_t e[8];
+    size_t pos = 0;
+    for (;;) {
         unsigned act = 0;
-        for (int k = 0; k < count; k++) {
-            const bool a = r < nn[k];
-            e[k] = a ? coded[k][r] : 0;
-            act |= unsigned(a) << k;
+        size_t m = SIZE_MAX;
+        for (int k = 0; k < count; k++)
+            if (len[k] > pos) { act |= 1u << k; if (len[k] < m) m = len[k]; }
+        if (!act) break;
+        const __mmask8 ka = (__mmask8)act;
+        for (; pos + 4 <= m; pos += 4) {
+            const __m512i addr = _mm512_add_epi64(vbase, _mm512_set1_epi64((long long)(2 * pos)));
+            const __m512i g = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), ka, addr, (const void *)0, 1);
+            step(L, g, ka);
+            step(L, _mm512_srli_epi64(g, 16), ka);
+            step(L, _mm512_srli_epi64(g, 32), ka);
+            step(L, _mm512_srli_epi64(g, 48), ka);
         }
-        for (int k = count; k < 8; k++) e[k] = 0;
-        step(L, _mm512_load_si512((const void *)e), (__mmask8)act);
+        for (; pos < m; pos++) {                              // at most three bins: the shortest lane's end
+            alignas(64) uint64_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < count; k++) if (act >> k & 1u) e[k] = src[k][pos];
+            step(L, _mm512_load_si512((const void *)e), ka);
+        }
     }
-    // leftovers of the byte accumulators, then the 4-byte flush of lo (NBLIC.c:576-586)
+}
+
+// Two packs advanced in lock-step.  One pack's step is a ~25-cycle dependent chain of ~35
+// instructions, so a core that interleaves two independent packs (sixteen images) nearly doubles
+// its throughput.  The joint loop runs while every active lane of both packs has four bins left;
+// the few bins after that go through the single-pack feed.
+NB_TARGET void feed_pair(RangeX8 &A, const uint16_t *const *src_a, const size_t *len_a,
+                         RangeX8 &B, const uint16_t *const *src_b, const size_t *len_b) {
+    Lanes &LA = A.st->L, &LB = B.st->L;
+    alignas(64) uint64_t base_a[8], base_b[8];
+    unsigned act_a = 0, act_b = 0;
+    size_t m = SIZE_MAX;
+    for (int k = 0; k < 8; k++) {
+        const bool a = k < A.st->count && len_a[k], b = k < B.st->count && len_b[k];
+        base_a[k] = a ? (uint64_t)(uintptr_t)src_a[k] : 0;
+        base_b[k] = b ? (uint64_t)(uintptr_t)src_b[k] : 0;
+        if (a) { act_a |= 1u << k; if (len_a[k] < m) m = len_a[k]; }
+        if (b) { act_b |= 1u << k; if (len_b[k] < m) m = len_b[k]; }
+    }
+    size_t pos = 0;
+    if (act_a && act_b) {
+        const __m512i va = _mm512_load_si512((const void *)base_a), vb = _mm512_load_si512((const void *)base_b);
+        const __mmask8 ka = (__mmask8)act_a, kb = (__mmask8)act_b;
+        for (; pos + 4 <= m; pos += 4) {
+            const __m512i off = _mm512_set1_epi64((long long)(2 * pos));
+            const __m512i ga = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), ka, _mm512_add_epi64(va, off), (const void *)0, 1);
+            const __m512i gb = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), kb, _mm512_add_epi64(vb, off), (const void *)0, 1);
+            step(LA, ga, ka);                         step(LB, gb, kb);
+            step(LA, _mm512_srli_epi64(ga, 16), ka);  step(LB, _mm512_srli_epi64(gb, 16), kb);
+            step(LA, _mm512_srli_epi64(ga, 32), ka);  step(LB, _mm512_srli_epi64(gb, 32), kb);
+            step(LA, _mm512_srli_epi64(ga, 48), ka);  step(LB, _mm512_srli_epi64(gb, 48), kb);
+        }
+    }
+    const uint16_t *ra[8], *rb[8]; size_t la[8], lb[8];
+    for (int k = 0; k < 8; k++) {
+        ra[k] = src_a[k] ? src_a[k] + pos : nullptr; la[k] = (act_a >> k & 1u) ? len_a[k] - pos : 0;
+        rb[k] = src_b[k] ? src_b[k] + pos : nullptr; lb[k] = (act_b >> k & 1u) ? len_b[k] - pos : 0;
+    }
+    A.feed(ra, la);
+    B.feed(rb, lb);
+}
+
+// leftovers of the byte accumulators, then the 4-byte flush of lo (NBLIC.c:576-586)
+NB_TARGET void RangeX8::end(size_t *lens) {
+    Lanes &L = st->L;
     alignas(64) uint64_t a[8], c[8], lo[8];
     _mm512_store_si512((void *)a, L.acc);
     _mm512_store_si512((void *)c, L.cnt);
     _mm512_store_si512((void *)lo, L.lo);
-    for (int k = 0; k < count; k++) {
+    for (int k = 0; k < st->count; k++) {
         uint8_t *p = L.outp[k];
         const int left = (int)c[k];
         if (L.overflow[k] || p + left + 4 > L.oend[k]) { lens[k] = SIZE_MAX; continue; }
         for (int i = left - 1; i >= 0; i--) *p++ = (uint8_t)(a[k] >> (8 * i));
         uint32_t v = (uint32_t)lo[k];
         for (int i = 0; i < 4; i++) { *p++ = (uint8_t)(v >> 24); v <<= 8; }
-        lens[k] = (size_t)(p - outs[k]);
+        lens[k] = (size_t)(p - st->out0[k]);
     }
+}
+
+// Codes `count` (<= 8) whole streams.  coded[k][0..n[k]) are u16 bins (prob | bin << 15); outs[k] has
+// caps[k] bytes.  lens[k] = bytes written (coder bytes + 4 flush bytes) or SIZE_MAX if it did not fit.
+void range_code_x8(const uint16_t *const *coded, const size_t *n, int count, uint8_t *const *outs,
+                   const size_t *caps, size_t *lens) {
+    if (count <= 0) return;
+    if (count > 8) {                                          // up to sixteen: two packs in lock-step
+        RangeX8 a, b;
+        a.begin(8, outs, caps);
+        b.begin(count - 8 < 8 ? count - 8 : 8, outs + 8, caps + 8);
+        const uint16_t *sb[8] = {nullptr}; size_t nb[8] = {0};
+        for (int k = 8; k < count && k < 16; k++) { sb[k - 8] = coded[k]; nb[k - 8] = n[k]; }
+        feed_pair(a, coded, n, b, sb, nb);
+        a.end(lens);
+        b.end(lens + 8);
+        return;
+    }
+    RangeX8 x;
+    x.begin(count, outs, caps);
+    x.feed(coded, n);
+    x.end(lens);
 }
 
 // Measured and rejected (EPYC 9575F): 2-4 streams interleaved in general-purpose registers.

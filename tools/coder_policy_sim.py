@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Discrete-event model behind the coder threads' take policy (pipeline.hip, coder_take).
+
+The GPU delivers groups of 8 images every ~29 ms after a ~100 ms ramp; a coder thread codes k
+images together in T(k) seconds (measured on the GPU box's EPYC 9575F: scalar 450 Mbins/s,
+8 AVX-512 lanes ~137 Mbins/s per lane, 16 lanes ~91 Mbins/s per lane; 74.5 Mbins per 4096x4096
+SYN-1 frame).  Prints the whole-batch Mpixel/s each policy would reach for several batch sizes.
+No GPU needed."""
+import heapq
+
+BINS = 74.5e6
+
+def T(k):
+    if k == 1: return BINS / 450e6
+    if k <= 8: return BINS / (151e6 - (k - 4) * 3.5e6 if k >= 4 else 155e6)
+    return BINS / (1460e6 / 16 + (16 - k) * 2.5e6)
+
+def run(B, policy, threads=16, t0=0.10, gap=0.029, group=8):
+    events = [(t0 + i * gap, 'a', group) for i in range(B // group)]
+    heapq.heapify(events)
+    q, to_come, idle, tend = 0, B, threads, 0.0
+    while events:
+        t, kind, n = heapq.heappop(events)
+        if kind == 'a': q += n; to_come -= n
+        else: idle += 1; tend = t
+        while idle > 0 and q > 0:
+            k = policy(q, to_come, threads, idle)
+            if k <= 0: break
+            k = min(k, q); q -= k; idle -= 1
+            heapq.heappush(events, (t + T(k), 'd', k))
+    return tend
+
+def idle_driven(mult, use16):
+    def pol(q, to_come, threads, idle):
+        left = q + to_come
+        if q >= 8 and idle == 1 and left >= mult * threads:
+            return 16 if (use16 and q >= 16 and left >= 8 * threads) else 8
+        return 1
+    return pol
+
+def even_share(q, to_come, threads, idle):
+    left = q + to_come; k = -(-left // threads)
+    if k < 3: return 1
+    want = 16 if k >= 14 else min(k, 8)
+    if q >= want: return want
+    return q if to_come == 0 else 0
+
+if __name__ == "__main__":
+    pols = {"singles": lambda *a: 1, "always-8": lambda q, *a: 8 if q >= 8 else 1, "even-share": even_share,
+            "idle-driven 8": idle_driven(3, 0), "idle-driven 8/16 (shipped)": idle_driven(3, 1)}
+    for B in (16, 64, 256, 512, 1024):
+        print("B=%4d  " % B + "  ".join("%s %.0f" % (n, B * 16.777216 / run(B, p)) for n, p in pols.items()))

@@ -10,5 +10,6 @@ for b in range(8):
     print(b, d[64 + b*4: 64 + b*4 + 4])
 print("counter chains > 100k touches: cycles, touches, windows, key")
 rows = d[256:256+1024].reshape(256, 4)
-for r in rows[rows[:,1] > 0]:
-    print(r, "cycles/window %.0f" % (r[0] / max(1, r[2])))
+for r in rows[rows[:,1] > 0][:10]:
+    print("cycles %d touches %d windows %d | cycles/window %.0f | halvings %d (%.2f/window)" % (
+        r[0], r[1], r[2], r[0] / max(1, r[2]), r[3], r[3] / max(1, r[2])))
