@@ -66,10 +66,12 @@ nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders);
 
 /* Same, with the split of the images in flight spelled out: n_groups groups of group_size
  * images.  A group shares every kernel launch (its serial chains run side by side); while the
- * host codes one group the GPU works on the next.  n_host_buffers (>= n_groups * group_size)
- * pinned host buffers hold coded-bin streams waiting for a coder thread, so the device
- * workspace of an image is free again as soon as its stream has been copied out.
- * nblic_amd_create uses two groups and 2 * n_slots host buffers.                              */
+ * host codes one group the GPU works on the next.  n_host_buffers (raised to at least
+ * n_groups * group_size + 16) buffers IN HBM hold coded-bin streams waiting for a coder thread,
+ * so the device workspace of an image is free again as soon as its kernels have finished; the
+ * coder threads stream the bins to the host through a small pinned ring of their own.  (The
+ * parameter keeps its name from when these buffers were pinned host memory.)
+ * nblic_amd_create uses two groups and 2 * n_slots buffers.                                   */
 nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int n_coders, int n_host_buffers);
 void nblic_amd_destroy(nblic_amd_ctx *ctx);
 

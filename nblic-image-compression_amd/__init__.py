@@ -20,6 +20,10 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
+# The batch pipeline keeps 6 group streams + 4 copy streams busy; the HIP runtime multiplexes
+# streams onto 4 hardware queues by default and reads this when it initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnblic_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
