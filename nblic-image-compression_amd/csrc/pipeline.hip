@@ -320,8 +320,10 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
         HIP_OK(hipEventRecord(t.ev[c & 1], t.stream));
         return true;
     };
-    if (take > 8) { t.x8.begin(8, dst, caps); t.x8b.begin(take - 8, dst + 8, caps + 8); }
-    else if (take > 1) t.x8.begin(take, dst, caps);
+    // two packs in lock-step whenever there is more than one image: a lone pack is bound by the
+    // latency of its own dependent chain, a second one rides along almost for free
+    const int na = take > 1 ? (take + 1) / 2 : 0, nb = take > 1 ? take - na : 0;
+    if (take > 1) { t.x8.begin(na, dst, caps); t.x8b.begin(nb, dst + na, caps + na); }
     else t.x1.begin(dst[0], caps[0]);
     if (chunks && !issue(0)) return false;
     for (size_t c = 0; c < chunks; c++) {
@@ -329,14 +331,12 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
         auto w0 = std::chrono::steady_clock::now();
         HIP_OK(hipEventSynchronize(t.ev[c & 1]));
         t.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-        const uint16_t *src[kMaxTake]; size_t len[kMaxTake];
-        for (int k = 0; k < kMaxTake; k++) { src[k] = t.slot(int(c & 1), k); len[k] = k < take ? chunk_len(c, k) : 0; }
-        if (take > 8) feed_pair(t.x8, src, len, t.x8b, src + 8, len + 8);
-        else if (take > 1) t.x8.feed(src, len);
+        const uint16_t *src[kMaxTake + 8]; size_t len[kMaxTake + 8];
+        for (int k = 0; k < kMaxTake + 8; k++) { src[k] = k < kMaxTake ? t.slot(int(c & 1), k) : nullptr; len[k] = k < take ? chunk_len(c, k) : 0; }
+        if (take > 1) feed_pair(t.x8, src, len, t.x8b, src + na, len + na);
         else t.x1.feed(src[0], len[0]);
     }
-    if (take > 8) { t.x8.end(lens); t.x8b.end(lens + 8); }
-    else if (take > 1) t.x8.end(lens);
+    if (take > 1) { t.x8.end(lens); t.x8b.end(lens + na); }
     else lens[0] = t.x1.finish();
     return true;
 }

@@ -21,69 +21,103 @@ namespace nblic {
 
 bool have_avx512() {
     return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
-           __builtin_cpu_supports("avx512vl");
+           __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512vbmi2");
 }
 
-#define NB_TARGET __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,bmi,bmi2,lzcnt")))
+#define NB_TARGET __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,avx512vbmi2,bmi,bmi2,lzcnt")))
 
 namespace {
 
-// Per lane the interval is kept as (lo, span = hi - lo): the multiply then depends on one value.
-struct Lanes {
-    __m512i lo, span, acc, cnt;
-    uint8_t *outp[8], *oend[8];
-    bool overflow[8];
-};
+#define NB_INLINE inline __attribute__((always_inline))
 
-NB_TARGET inline void flush_full(Lanes &L, __mmask8 kf) {
+// Per lane the interval is kept as (lo, span = hi - lo): the multiply then depends on one value.
+// The four vectors live in REGISTERS for the whole of a feed() call: they are copied out of the
+// persistent state at its start and back at its end, and every helper below is force-inlined --
+// passed around by reference to memory, each step's interval update went through a 64-byte store
+// and reload, and that round trip, not the arithmetic, set the pace.
+struct Regs { __m512i lo, span, acc, cnt; };
+struct Outs { uint8_t *outp[8], *oend[8]; bool overflow[8]; };
+struct Lanes { Regs r; Outs o; };
+
+NB_TARGET NB_INLINE void flush_full(Regs &R, Outs &O, __mmask8 kf) {
     alignas(64) uint64_t a[8];
-    _mm512_store_si512((void *)a, L.acc);
+    _mm512_store_si512((void *)a, R.acc);
     unsigned m = kf;
     while (m) {
         int k = __builtin_ctz(m);
         m &= m - 1;
-        if (L.outp[k] + 8 <= L.oend[k]) {
+        if (O.outp[k] + 8 <= O.oend[k]) {
             uint64_t be = __builtin_bswap64(a[k]);
-            __builtin_memcpy(L.outp[k], &be, 8);
+            __builtin_memcpy(O.outp[k], &be, 8);
         } else {
-            L.overflow[k] = true;
+            O.overflow[k] = true;
         }
-        L.outp[k] += 8;
+        O.outp[k] += 8;
     }
-    L.cnt = _mm512_mask_mov_epi64(L.cnt, kf, _mm512_setzero_si512());
+    R.cnt = _mm512_mask_mov_epi64(R.cnt, kf, _mm512_setzero_si512());
 }
 
 // lanes in k shift one byte out (NBLIC.c:563-572); returns the lanes that must shift again
-NB_TARGET inline __mmask8 renorm_once(Lanes &L, __mmask8 k) {
+NB_TARGET NB_INLINE __mmask8 renorm_once(Regs &R, Outs &O, __mmask8 k) {
     const __m512i m32 = _mm512_set1_epi64(0xFFFFFFFFll), top = _mm512_set1_epi64(0xFF000000ll);
-    const __m512i hi = _mm512_add_epi64(L.lo, L.span);
-    k = _mm512_mask_testn_epi64_mask(k, _mm512_xor_si512(L.lo, hi), top);                // top bytes agree
-    L.acc = _mm512_mask_or_epi64(L.acc, k, _mm512_slli_epi64(L.acc, 8), _mm512_srli_epi64(hi, 24));
-    L.cnt = _mm512_mask_add_epi64(L.cnt, k, L.cnt, _mm512_set1_epi64(1));
-    L.lo = _mm512_mask_and_epi64(L.lo, k, _mm512_slli_epi64(L.lo, 8), m32);
-    L.span = _mm512_mask_or_epi64(L.span, k, _mm512_slli_epi64(L.span, 8), _mm512_set1_epi64(0xFF));   // span < 2^24 here
-    const __mmask8 kf = _mm512_mask_cmpeq_epi64_mask(k, L.cnt, _mm512_set1_epi64(8));
-    if (__builtin_expect(kf != 0, 0)) flush_full(L, kf);
+    const __m512i hi = _mm512_add_epi64(R.lo, R.span);
+    k = _mm512_mask_testn_epi64_mask(k, _mm512_xor_si512(R.lo, hi), top);                // top bytes agree
+    R.acc = _mm512_mask_or_epi64(R.acc, k, _mm512_slli_epi64(R.acc, 8), _mm512_srli_epi64(hi, 24));
+    R.cnt = _mm512_mask_add_epi64(R.cnt, k, R.cnt, _mm512_set1_epi64(1));
+    R.lo = _mm512_mask_and_epi64(R.lo, k, _mm512_slli_epi64(R.lo, 8), m32);
+    R.span = _mm512_mask_or_epi64(R.span, k, _mm512_slli_epi64(R.span, 8), _mm512_set1_epi64(0xFF));   // span < 2^24 here
+    const __mmask8 kf = _mm512_mask_cmpeq_epi64_mask(k, R.cnt, _mm512_set1_epi64(8));
+    if (__builtin_expect(kf != 0, 0)) flush_full(R, O, kf);
     return k;
 }
 
 // one bin per active lane; ev holds prob | bin << 15 in the low 16 bits of every lane
-NB_TARGET inline void step(Lanes &L, __m512i ev, __mmask8 kact) {
+NB_TARGET NB_INLINE void step(Regs &R, Outs &O, __m512i ev, __mmask8 kact) {
     const __m512i prob = _mm512_and_si512(ev, _mm512_set1_epi64(0xFFF));
-    const __m512i t1 = _mm512_add_epi64(_mm512_srli_epi64(_mm512_mul_epu32(L.span, prob), 12), _mm512_set1_epi64(1));
+    const __m512i t1 = _mm512_add_epi64(_mm512_srli_epi64(_mm512_mul_epu32(R.span, prob), 12), _mm512_set1_epi64(1));
     const __mmask8 kone = _mm512_test_epi64_mask(ev, _mm512_set1_epi64(0x8000));
     const __mmask8 k1 = kone & kact, k0 = (__mmask8)(~kone) & kact;
     // bin 1 keeps [lo, cut]: span = t; bin 0 keeps [cut + 1, hi]: lo += t + 1, span -= t + 1
-    L.lo = _mm512_mask_add_epi64(L.lo, k0, L.lo, t1);
-    L.span = _mm512_mask_sub_epi64(L.span, k0, L.span, t1);
-    L.span = _mm512_mask_sub_epi64(L.span, k1, t1, _mm512_set1_epi64(1));
-    __mmask8 k = renorm_once(L, kact);                       // first byte: executed unconditionally, usually a no-op
+    R.lo = _mm512_mask_add_epi64(R.lo, k0, R.lo, t1);
+    R.span = _mm512_mask_sub_epi64(R.span, k0, R.span, t1);
+    R.span = _mm512_mask_sub_epi64(R.span, k1, t1, _mm512_set1_epi64(1));
+    __mmask8 k = renorm_once(R, O, kact);                    // first byte: executed unconditionally, usually a no-op
     // a second byte in the same step is rare: test before doing the masked work again
     const __m512i top = _mm512_set1_epi64(0xFF000000ll);
-    k = _mm512_mask_testn_epi64_mask(k, _mm512_xor_si512(L.lo, _mm512_add_epi64(L.lo, L.span)), top);
+    k = _mm512_mask_testn_epi64_mask(k, _mm512_xor_si512(R.lo, _mm512_add_epi64(R.lo, R.span)), top);
     while (__builtin_expect(k != 0, 0)) {
-        renorm_once(L, k);
-        k = _mm512_mask_testn_epi64_mask(k, _mm512_xor_si512(L.lo, _mm512_add_epi64(L.lo, L.span)), top);
+        renorm_once(R, O, k);
+        k = _mm512_mask_testn_epi64_mask(k, _mm512_xor_si512(R.lo, _mm512_add_epi64(R.lo, R.span)), top);
+    }
+}
+
+// The same step when EVERY lane of the register may be updated (all streams of the pack alive;
+// lanes beyond the pack's count hold nothing that is kept) -- the steady state, so it is written
+// for instruction count: no activity mask, the bin-0 mask straight from a test-not, the interval
+// update as two masked operations, and ONE rarely-taken branch for everything unusual (a full byte
+// accumulator, a second byte in the same step).
+NB_TARGET NB_INLINE void step_all(Regs &R, Outs &O, __m512i ev) {
+    const __m512i tm = _mm512_srli_epi64(_mm512_mul_epu32(R.span, _mm512_and_si512(ev, _mm512_set1_epi64(0xFFF))), 12);
+    const __m512i t1 = _mm512_add_epi64(tm, _mm512_set1_epi64(1));
+    const __mmask8 k0 = _mm512_testn_epi64_mask(ev, _mm512_set1_epi64(0x8000));           // lanes whose bin is 0
+    R.lo = _mm512_mask_add_epi64(R.lo, k0, R.lo, t1);                                        // bin 0: lo += t + 1
+    R.span = _mm512_mask_sub_epi64(tm, k0, R.span, t1);                                      // bin 0: span -= t + 1; bin 1: span = t
+    const __m512i hi = _mm512_add_epi64(R.lo, R.span);
+    const __m512i x = _mm512_xor_si512(R.lo, hi);
+    const __mmask8 k = _mm512_testn_epi64_mask(x, _mm512_set1_epi64(0xFF000000ll));         // top bytes agree: one byte out
+    const __mmask8 k2 = _mm512_testn_epi64_mask(x, _mm512_set1_epi64(0xFFFF0000ll));        // top two bytes agree (rare)
+    R.acc = _mm512_mask_shldi_epi64(R.acc, k, R.acc, _mm512_slli_epi64(hi, 32), 8);          // acc = acc << 8 | hi >> 24
+    R.cnt = _mm512_mask_add_epi64(R.cnt, k, R.cnt, _mm512_set1_epi64(1));
+    R.lo = _mm512_mask_and_epi64(R.lo, k, _mm512_slli_epi64(R.lo, 8), _mm512_set1_epi64(0xFFFFFFFFll));
+    R.span = _mm512_mask_or_epi64(R.span, k, _mm512_slli_epi64(R.span, 8), _mm512_set1_epi64(0xFF));
+    const __mmask8 kf = _mm512_cmpeq_epi64_mask(R.cnt, _mm512_set1_epi64(8));
+    if (__builtin_expect((kf | k2) != 0, 0)) {
+        if (kf) flush_full(R, O, kf);
+        __mmask8 kk = k2;
+        while (kk) {                                          // further bytes of the same step, one at a time
+            renorm_once(R, O, kk);
+            kk = _mm512_mask_testn_epi64_mask(kk, _mm512_xor_si512(R.lo, _mm512_add_epi64(R.lo, R.span)), _mm512_set1_epi64(0xFF000000ll));
+        }
     }
 }
 
@@ -101,22 +135,23 @@ NB_TARGET void RangeX8::begin(int count, uint8_t *const *outs, const size_t *cap
     Lanes &L = st->L;
     st->count = count;
     for (int k = 0; k < 8; k++) {
-        L.outp[k] = k < count ? outs[k] : nullptr;
-        L.oend[k] = k < count ? outs[k] + caps[k] : nullptr;
-        L.overflow[k] = false;
-        st->out0[k] = L.outp[k];
+        L.o.outp[k] = k < count ? outs[k] : nullptr;
+        L.o.oend[k] = k < count ? outs[k] + caps[k] : nullptr;
+        L.o.overflow[k] = false;
+        st->out0[k] = L.o.outp[k];
     }
-    L.lo = _mm512_setzero_si512();
-    L.span = _mm512_set1_epi64(0xFFFFFFFFll);
-    L.acc = _mm512_setzero_si512();
-    L.cnt = _mm512_setzero_si512();
+    L.r.lo = _mm512_setzero_si512();
+    L.r.span = _mm512_set1_epi64(0xFFFFFFFFll);
+    L.r.acc = _mm512_setzero_si512();
+    L.r.cnt = _mm512_setzero_si512();
 }
 
 // Lane k codes src[k][0 .. len[k]) (len 0 = lane idle in this chunk).  While every active lane has
 // four bins left, one 8-byte gather per lane brings the next four bins of every stream; lanes drop
 // out of the mask as their chunk ends.
 NB_TARGET void RangeX8::feed(const uint16_t *const *src, const size_t *len) {
-    Lanes &L = st->L;
+    Regs R = st->L.r;
+    Outs &O = st->L.o;
     const int count = st->count;
     alignas(64) uint64_t base[8];
     for (int k = 0; k < 8; k++) base[k] = (k < count && len[k]) ? (uint64_t)(uintptr_t)src[k] : 0;
@@ -129,20 +164,31 @@ NB_TARGET void RangeX8::feed(const uint16_t *const *src, const size_t *len) {
             if (len[k] > pos) { act |= 1u << k; if (len[k] < m) m = len[k]; }
         if (!act) break;
         const __mmask8 ka = (__mmask8)act;
+        if (act == (1u << count) - 1u) {                      // every stream of the pack alive
+            for (; pos + 4 <= m; pos += 4) {
+                const __m512i addr = _mm512_add_epi64(vbase, _mm512_set1_epi64((long long)(2 * pos)));
+                const __m512i g = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), ka, addr, (const void *)0, 1);
+                step_all(R, O, g);
+                step_all(R, O, _mm512_srli_epi64(g, 16));
+                step_all(R, O, _mm512_srli_epi64(g, 32));
+                step_all(R, O, _mm512_srli_epi64(g, 48));
+            }
+        }
         for (; pos + 4 <= m; pos += 4) {
             const __m512i addr = _mm512_add_epi64(vbase, _mm512_set1_epi64((long long)(2 * pos)));
             const __m512i g = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), ka, addr, (const void *)0, 1);
-            step(L, g, ka);
-            step(L, _mm512_srli_epi64(g, 16), ka);
-            step(L, _mm512_srli_epi64(g, 32), ka);
-            step(L, _mm512_srli_epi64(g, 48), ka);
+            step(R, O, g, ka);
+            step(R, O, _mm512_srli_epi64(g, 16), ka);
+            step(R, O, _mm512_srli_epi64(g, 32), ka);
+            step(R, O, _mm512_srli_epi64(g, 48), ka);
         }
         for (; pos < m; pos++) {                              // at most three bins: the shortest lane's end
             alignas(64) uint64_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int k = 0; k < count; k++) if (act >> k & 1u) e[k] = src[k][pos];
-            step(L, _mm512_load_si512((const void *)e), ka);
+            step(R, O, _mm512_load_si512((const void *)e), ka);
         }
     }
+    st->L.r = R;
 }
 
 // Two packs advanced in lock-step.  One pack's step is a ~25-cycle dependent chain of ~35
@@ -151,7 +197,8 @@ NB_TARGET void RangeX8::feed(const uint16_t *const *src, const size_t *len) {
 // the few bins after that go through the single-pack feed.
 NB_TARGET void feed_pair(RangeX8 &A, const uint16_t *const *src_a, const size_t *len_a,
                          RangeX8 &B, const uint16_t *const *src_b, const size_t *len_b) {
-    Lanes &LA = A.st->L, &LB = B.st->L;
+    Regs RA = A.st->L.r, RB = B.st->L.r;
+    Outs &OA = A.st->L.o, &OB = B.st->L.o;
     alignas(64) uint64_t base_a[8], base_b[8];
     unsigned act_a = 0, act_b = 0;
     size_t m = SIZE_MAX;
@@ -163,19 +210,21 @@ NB_TARGET void feed_pair(RangeX8 &A, const uint16_t *const *src_a, const size_t 
         if (b) { act_b |= 1u << k; if (len_b[k] < m) m = len_b[k]; }
     }
     size_t pos = 0;
-    if (act_a && act_b) {
+    if (act_a == (1u << A.st->count) - 1u && act_b == (1u << B.st->count) - 1u) {
         const __m512i va = _mm512_load_si512((const void *)base_a), vb = _mm512_load_si512((const void *)base_b);
         const __mmask8 ka = (__mmask8)act_a, kb = (__mmask8)act_b;
         for (; pos + 4 <= m; pos += 4) {
             const __m512i off = _mm512_set1_epi64((long long)(2 * pos));
             const __m512i ga = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), ka, _mm512_add_epi64(va, off), (const void *)0, 1);
             const __m512i gb = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), kb, _mm512_add_epi64(vb, off), (const void *)0, 1);
-            step(LA, ga, ka);                         step(LB, gb, kb);
-            step(LA, _mm512_srli_epi64(ga, 16), ka);  step(LB, _mm512_srli_epi64(gb, 16), kb);
-            step(LA, _mm512_srli_epi64(ga, 32), ka);  step(LB, _mm512_srli_epi64(gb, 32), kb);
-            step(LA, _mm512_srli_epi64(ga, 48), ka);  step(LB, _mm512_srli_epi64(gb, 48), kb);
+            step_all(RA, OA, ga);                         step_all(RB, OB, gb);
+            step_all(RA, OA, _mm512_srli_epi64(ga, 16));  step_all(RB, OB, _mm512_srli_epi64(gb, 16));
+            step_all(RA, OA, _mm512_srli_epi64(ga, 32));  step_all(RB, OB, _mm512_srli_epi64(gb, 32));
+            step_all(RA, OA, _mm512_srli_epi64(ga, 48));  step_all(RB, OB, _mm512_srli_epi64(gb, 48));
         }
     }
+    A.st->L.r = RA;
+    B.st->L.r = RB;
     const uint16_t *ra[8], *rb[8]; size_t la[8], lb[8];
     for (int k = 0; k < 8; k++) {
         ra[k] = src_a[k] ? src_a[k] + pos : nullptr; la[k] = (act_a >> k & 1u) ? len_a[k] - pos : 0;
@@ -189,13 +238,13 @@ NB_TARGET void feed_pair(RangeX8 &A, const uint16_t *const *src_a, const size_t 
 NB_TARGET void RangeX8::end(size_t *lens) {
     Lanes &L = st->L;
     alignas(64) uint64_t a[8], c[8], lo[8];
-    _mm512_store_si512((void *)a, L.acc);
-    _mm512_store_si512((void *)c, L.cnt);
-    _mm512_store_si512((void *)lo, L.lo);
+    _mm512_store_si512((void *)a, L.r.acc);
+    _mm512_store_si512((void *)c, L.r.cnt);
+    _mm512_store_si512((void *)lo, L.r.lo);
     for (int k = 0; k < st->count; k++) {
-        uint8_t *p = L.outp[k];
+        uint8_t *p = L.o.outp[k];
         const int left = (int)c[k];
-        if (L.overflow[k] || p + left + 4 > L.oend[k]) { lens[k] = SIZE_MAX; continue; }
+        if (L.o.overflow[k] || p + left + 4 > L.o.oend[k]) { lens[k] = SIZE_MAX; continue; }
         for (int i = left - 1; i >= 0; i--) *p++ = (uint8_t)(a[k] >> (8 * i));
         uint32_t v = (uint32_t)lo[k];
         for (int i = 0; i < 4; i++) { *p++ = (uint8_t)(v >> 24); v <<= 8; }
