@@ -183,6 +183,7 @@ struct nblic_amd_ctx {
     double total_bins = 0, coder_s = 0;
     double pack_bins = 0, pack_s = 0;     // the part of the above coded eight at a time
     double wait_s = 0;                    // of coder_s: waiting for bins to arrive from HBM
+    long takes[kMaxTake + 1] = {0};       // how many times a thread took k images together
     std::mutex stat_m;
     SerialEngine serial;
 };
@@ -341,21 +342,20 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
     return true;
 }
 
-// Coder thread.  Measured on the GPU box (EPYC 9575F), per thread: one stream alone 440-510
-// Mbins/s, eight streams in the lanes of one AVX-512 register 1095 Mbins/s together, two such
-// packs in lock-step 1460 Mbins/s -- at 3x / 4.6x the latency of a stream coded alone.  The
-// host's CPU share, not the GPU, bounds the pipeline, so under load the threads must work in
-// packs; but a short batch, and the tail of a long one, finish sooner as singles spread over the
-// threads.  Policy (picked with a discrete-event model of arrivals and coder speeds, tools/
-// coder_policy_sim.py): a single while any other thread is idle, a pack of eight when this is the
-// only idle thread and plenty of work is left, sixteen when there is plenty queued as well.
+// Coder thread.  Measured on the GPU box (EPYC 9575F), per thread: one stream alone 400-510
+// Mbins/s; packs always run as two AVX-512 registers in lock-step: 2 x 4 images 1300 Mbins/s,
+// 2 x 8 images 1875 Mbins/s -- at 2.5x / 3.4x the latency of a stream coded alone.  The host's
+// CPU share, not the GPU, bounds the pipeline, so a thread takes everything that is queued (up to
+// sixteen) as one pack; only when no more images are left than there are threads -- a short
+// batch, or the very tail of a long one -- does each image go to a thread of its own.  (Policy
+// picked with a discrete-event model of arrivals and coder speeds, tools/coder_policy_sim.py.)
 static int coder_take(const nblic_amd_ctx *c) {                  // call with c->rm held; 0 = nothing to take
     const size_t q = c->ready.size();
     if (q == 0) return 0;
     if (c->ready.front().kind != 0 || !c->simd) return 1;
     const size_t left = q + size_t(c->batch_to_come), threads = c->coders.size();
-    if (q >= 8 && c->idle_coders == 1 && left >= 3 * threads) return (q >= size_t(kMaxTake) && left >= 8 * threads) ? kMaxTake : 8;
-    return 1;
+    if (left <= threads) return 1;
+    return int(q < size_t(kMaxTake) ? q : size_t(kMaxTake));
 }
 
 static void coder_main(nblic_amd_ctx *c, int index) {
@@ -423,7 +423,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
             im[k].lens[im[k].job] = lens[k] == SIZE_MAX ? -1 : long(kHeaderBytes + lens[k]);
         }
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; if (take > 1) { c->pack_bins += bins; c->pack_s += dt; } c->wait_s += t.wait_s; t.wait_s = 0; }
+        { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; if (take > 1) { c->pack_bins += bins; c->pack_s += dt; } c->wait_s += t.wait_s; t.wait_s = 0; c->takes[take]++; }
         {
             std::lock_guard<std::mutex> l(c->fm);
             for (int k = 0; k < take; k++) c->free_cbufs.push_back(im[k].cb);
@@ -549,7 +549,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
     if (hipSetDevice(c->device) != hipSuccess) return false;
     for (auto &v : c->stage_ms) v = 0;
     c->stage_launches = 0;
-    c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0;
+    c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; for (auto &v : c->takes) v = 0;
     bool ok = true;
     c->failed = false;
     for (int k = 0; k < n_images; k++) lens[k] = -1;
@@ -584,7 +584,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
         fprintf(stderr, "[nblic_amd] coder: singles %.0f Mbins in %.2f thread-s (%.0f Mbins/s), packs %.0f Mbins in %.2f thread-s (%.0f Mbins/s)\n",
                 (c->total_bins - c->pack_bins) / 1e6, c->coder_s - c->pack_s, (c->total_bins - c->pack_bins) / 1e6 / (c->coder_s - c->pack_s + 1e-9),
                 c->pack_bins / 1e6, c->pack_s, c->pack_bins / 1e6 / (c->pack_s + 1e-9)),
-        fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that waiting for chunks\n", c->wait_s);
+        fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that waiting for chunks; takes of 1/2-7/8/9-15/16 images: %ld/%ld/%ld/%ld/%ld\n", c->wait_s, c->takes[1], c->takes[2] + c->takes[3] + c->takes[4] + c->takes[5] + c->takes[6] + c->takes[7], c->takes[8], c->takes[9] + c->takes[10] + c->takes[11] + c->takes[12] + c->takes[13] + c->takes[14] + c->takes[15], c->takes[16]);
     for (int k = 0; k < n_images; k++) if (lens[k] < 0) ok = false;
     return ok && !c->failed;
 }

@@ -11,9 +11,10 @@ import heapq
 BINS = 74.5e6
 
 def T(k):
-    if k == 1: return BINS / 450e6
-    if k <= 8: return BINS / (151e6 - (k - 4) * 3.5e6 if k >= 4 else 155e6)
-    return BINS / (1460e6 / 16 + (16 - k) * 2.5e6)
+    """seconds a thread needs for k images together (in-situ rates, Mbins/s per thread)"""
+    if k == 1: return BINS / 400e6
+    rate = 650e6 * min(k, 8) / 4 if k <= 4 else (1300e6 + (k - 8) * 72e6 if k >= 8 else 650e6 + (k - 4) * 162e6)   # 2x2..2x4 lanes, then up to 2x8 = 1875
+    return BINS * k / rate
 
 def run(B, policy, threads=16, t0=0.10, gap=0.029, group=8):
     events = [(t0 + i * gap, 'a', group) for i in range(B // group)]
@@ -46,7 +47,16 @@ def even_share(q, to_come, threads, idle):
     return q if to_come == 0 else 0
 
 if __name__ == "__main__":
+    def greedy(q, to_come, threads, idle):               # as many as are queued, up to 16
+        return min(q, 16)
+    def greedy_tail(mult):
+        def pol(q, to_come, threads, idle):
+            left = q + to_come
+            if left < mult * threads: return 1 if left < 2 * threads else min(q, max(1, -(-left // threads)))
+            return min(q, 16)
+        return pol
     pols = {"singles": lambda *a: 1, "always-8": lambda q, *a: 8 if q >= 8 else 1, "even-share": even_share,
-            "idle-driven 8": idle_driven(3, 0), "idle-driven 8/16 (shipped)": idle_driven(3, 1)}
+            "idle-driven 8": idle_driven(3, 0), "idle-driven 8/16": idle_driven(3, 1), "greedy<=16": greedy,
+            "greedy+tail4": greedy_tail(4), "greedy+tail8": greedy_tail(8)}
     for B in (16, 64, 256, 512, 1024):
         print("B=%4d  " % B + "  ".join("%s %.0f" % (n, B * 16.777216 / run(B, p)) for n, p in pols.items()))
