@@ -29,6 +29,7 @@ bool have_avx512() {
 namespace {
 
 #define NB_INLINE inline __attribute__((always_inline))
+constexpr size_t kPrefetchAhead = 1024;                       // bytes; sixteen gathered streams defeat the hardware prefetcher
 
 // Per lane the interval is kept as (lo, span = hi - lo): the multiply then depends on one value.
 // The four vectors live in REGISTERS for the whole of a feed() call: they are copied out of the
@@ -214,6 +215,12 @@ NB_TARGET void feed_pair(RangeX8 &A, const uint16_t *const *src_a, const size_t 
         const __m512i va = _mm512_load_si512((const void *)base_a), vb = _mm512_load_si512((const void *)base_b);
         const __mmask8 ka = (__mmask8)act_a, kb = (__mmask8)act_b;
         for (; pos + 4 <= m; pos += 4) {
+            if ((pos & 31) == 0) {                            // one 64-byte line per stream per 32 bins: ask for it early
+                for (int k = 0; k < 8; k++) {
+                    _mm_prefetch((const char *)base_a[k] + 2 * pos + kPrefetchAhead, _MM_HINT_T0);
+                    _mm_prefetch((const char *)base_b[k] + 2 * pos + kPrefetchAhead, _MM_HINT_T0);
+                }
+            }
             const __m512i off = _mm512_set1_epi64((long long)(2 * pos));
             const __m512i ga = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), ka, _mm512_add_epi64(va, off), (const void *)0, 1);
             const __m512i gb = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), kb, _mm512_add_epi64(vb, off), (const void *)0, 1);
