@@ -39,7 +39,7 @@ struct E1Buffers {
     int      *cnt_state;     // 4096 * 2
     uint32_t *events;        // ev_cap        model.h pack_event
     uint16_t *tin;           // 2*ev_cap+pad  touch payloads grouped by counter
-    uint64_t *tpos;          // ev_cap        {position of the tree-u touch, of the tree-v touch}
+    uint64_t *tpos;          // ev_cap + 64   two u32 arrays (even trees, odd trees): position of the event's touch in tin/tout, or ~0
     uint16_t *tout;          // 2*ev_cap+pad  P(bin==1) before each touch, same order as tin
     uint32_t *blk_base;      // 2049          first block of every context chain (+ total)
     int      *blk_end;       // n/4096+2048   context state at the end of each block

@@ -95,6 +95,12 @@ __device__ __forceinline__ uint32_t prob_one(int c1, int sum) {
     return uint32_t(q);
 }
 
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, uint32_t(__shfl_xor(int(v), d, 64)));
+    return v;
+}
+
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); }
 // v_writelane_b32: lane `l` of the result takes the uniform `value`, the other lanes keep `old`
 template <int L>
@@ -589,37 +595,159 @@ __global__ void __launch_bounds__(256) k_touch_count(const E1Job *__restrict__ j
     for (int k = lane_id(); k < 4096; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
 }
 
-// tpos[2r] / tpos[2r+1] = where event r's tree-u / tree-v probability will appear in tout[]
+// One wave per (segment, parity): places its segment's touches of that parity in the chains and
+// records where, posP[parity][r] = position of event r's touch in tin[] / tout[] (or kNoTouch).
+//
+// Written naively this kernel turns every touch into a scattered 2-byte store, and with ~2000
+// waves each appending to a few hundred chains far more 64-byte lines are open at once than L2 and
+// the MALL hold: measured 7x write amplification on tin[].  But 99 % of the touches fall in at most
+// a few hundred of the 4096 chains, and the partition table already says how many touches each
+// chain gets from this segment.  So the wave gives its kStageSlots busiest chains an LDS ring each
+// and writes those chains in whole aligned 64-byte lines:
+//   invariant per staged chain:  tin[.. flushed) is in HBM, [flushed, off) sits in the ring,
+//                                flushed >= off & ~31, so a group of <= 32 new touches always fits
+//                                (flushed lives in a register: lane s holds it for slot s);
+//   a group of more than 32 (flat images) goes straight to HBM after the ring has been drained.
+constexpr int kStageSlots = 64, kStageRing = 64;
+constexpr uint32_t kNoTouch = 0xFFFFFFFFu;
+struct alignas(16) TouchLds {
+    uint32_t off[2048];                      // next position of every chain of this parity
+    uint16_t ring[kStageSlots][kStageRing];
+    uint16_t slot_key[kStageSlots];
+    uint8_t slot[2048];                      // chain -> staging slot + 1, 0 = not staged
+};
+
+// The whole wave copies ring entries [a, b) of one staged chain to tin[]: a lane per touch, so the
+// store is one coalesced run whatever the alignment of a.  (b - a <= 63.)
+__device__ __forceinline__ void flush_range(TouchLds &L, NB_GLOBAL uint16_t *tin, int sl, uint32_t a, uint32_t b) {
+    const uint32_t e = a + uint32_t(lane_id());
+    if (e < b) tin[e] = L.ring[sl][e & (kStageRing - 1)];
+}
+
 __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__ jobs) {
-    __shared__ uint32_t lds[4][4096];
+    __shared__ TouchLds lds[4];
     const E1Job &J = jobs[blockIdx.y];
     const auto events = gptr(J.b.events); const auto table = gptr(J.b.table);
-    const auto tin = gptr(J.b.tin); const auto tpos = (NB_GLOBAL u32x2 *)gptr(J.b.tpos);
+    const auto tin = gptr(J.b.tin);
     const uint32_t n_ev = J.n_ev; const SegPlan plan = J.pe;
-    int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+    const int parity = int(blockIdx.z);
+    const auto posP = (NB_GLOBAL uint32_t *)gptr(J.b.tpos) + size_t(parity) * ((size_t(n_ev) + 63) & ~size_t(63));
+    const int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
-    uint32_t *off = lds[threadIdx.x >> 6];
-    for (int k = lane_id(); k < 4096; k += 64) off[k] = table[size_t(k) * plan.nseg + seg];
-    uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n_ev, lo + plan.seg_len);
-    for (uint32_t base = lo; base < hi; base += 64) {
-        uint32_t r = base + lane_id();
-        uint32_t e = r < hi ? events[r] : 0u;
-        uint32_t pos_u = 0, pos_v = 0;
-        bool have_v = false;
+    TouchLds &L = lds[threadIdx.x >> 6];
+    const int lane = lane_id();
+    const bool stamp = (J.dbg & 8) != 0;
+    unsigned long long t_begin = __builtin_amdgcn_s_memtime(), t_match = 0, t_place = 0, t_close = 0, t0 = 0;
+    // chain starts and this segment's touch count per chain (32 chains per lane)
+    uint32_t cnt[32], most = 0;
 #pragma unroll
-        for (int parity = 0; parity < 2; parity++) {
-            Touch t = touch_of(e, parity);
-            bool valid = r < hi && t.valid;
-            uint64_t same = match_lanes<11>(t.key, valid);       // the parity bit is common to the pass
-            if (valid) {
-                uint32_t rank = __popcll(same & lanes_below());
-                uint32_t pos = off[t.key] + rank;
-                tin[pos] = uint16_t(t.payload);
-                if (t.slot) { pos_v = pos; have_v = true; } else pos_u = pos;
-                if (rank == 0) off[t.key] += uint32_t(__popcll(same));
-            }
+    for (int i = 0; i < 32; i++) {
+        const int key = lane + 64 * i, gk = parity * 2048 + key;
+        const uint32_t start = table[size_t(gk) * plan.nseg + seg];
+        const uint32_t next = seg + 1 < plan.nseg ? table[size_t(gk) * plan.nseg + seg + 1]
+                            : (gk + 1 < 4096 ? table[size_t(gk + 1) * plan.nseg] : gptr(J.b.totals)[3]);
+        L.off[key] = start;
+        cnt[i] = next - start;
+        most = max(most, cnt[i]);
+    }
+    // the smallest threshold that leaves at most kStageSlots chains (binary search, wave-uniform)
+    most = wave_max(most);
+    uint32_t th_lo = 16, th_hi = max(most + 1, 17u);         // a chain with < 16 touches never fills a line
+    while (th_lo < th_hi) {
+        const uint32_t mid = (th_lo + th_hi) >> 1;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) mine += uint32_t(cnt[i] >= mid);
+        if (read_lane(wave_scan_incl_dpp(mine), 63) <= uint32_t(kStageSlots)) th_hi = mid; else th_lo = mid + 1;
+    }
+    {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) mine += uint32_t(cnt[i] >= th_lo);
+        uint32_t id = wave_scan_incl_dpp(mine) - mine;
+        L.slot_key[lane] = 0xFFFFu;                           // lane = slot; unused slots stay marked
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int key = lane + 64 * i;
+            const bool staged = cnt[i] >= th_lo && id < uint32_t(kStageSlots);
+            L.slot[key] = staged ? uint8_t(id + 1) : uint8_t(0);
+            if (staged) { L.slot_key[id] = uint16_t(key); id++; }
         }
-        if (r < hi) tpos[r] = u32x2{pos_u, have_v ? pos_v : pos_u};
+    }
+    const uint32_t my_key = L.slot_key[lane];                 // lane s looks after staging slot s
+    uint32_t my_flushed = my_key != 0xFFFFu ? L.off[my_key] : 0u;
+    const uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n_ev, lo + plan.seg_len);
+    auto place = [&](const uint32_t base, const uint32_t e) {
+        const uint32_t r = base + lane;
+        const Touch t = touch_of(e, parity);
+        const bool valid = r < hi && t.valid;
+        const uint32_t key = t.key & 2047u;
+        if (stamp) t0 = __builtin_amdgcn_s_memtime();
+        const uint32_t chain_off = L.off[key];                  // asked for before the ballots, consumed after them
+        const int chain_slot = int(L.slot[key]) - 1;
+        const uint64_t same = match_lanes<11>(key, valid);
+        if (stamp) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_match += t1 - t0; t0 = t1; }
+        uint32_t pos = kNoTouch;
+        int slv = -1;
+        if (valid) {
+            const uint32_t rank = __popcll(same & lanes_below());
+            slv = chain_slot;
+            pos = chain_off + rank;
+            if (slv >= 0 && __popcll(same) <= 32) L.ring[slv][pos & (kStageRing - 1)] = uint16_t(t.payload);
+            else tin[pos] = uint16_t(t.payload);
+        }
+        if (stamp) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_place += t1 - t0; t0 = t1; }
+        // one lane per chain closes the step; completed lines are then written by the whole wave.
+        // flushed lies in old's own 32-touch line (invariant), so whether a line was completed can be
+        // read off the positions alone.
+        const uint32_t group = uint32_t(__popcll(same));
+        const bool leader = valid && (same & lanes_below()) == 0;
+        const uint32_t old = pos, now = old + group;            // (leader: rank 0, so pos is the chain's old offset)
+        if (leader) L.off[key] = now;
+        const int sl = leader ? slv : -1;
+        uint64_t todo = __ballot(sl >= 0 && (group > 32 || (now >> 5) > (old >> 5)));
+        while (todo) {                                          // wave-uniform; ~1.5 lines per row
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const int s_sl = __builtin_amdgcn_readlane(sl, src);
+            const uint32_t s_old = read_lane(old, src), s_now = read_lane(now, src);
+            const bool big = read_lane(group, src) > 32;        // its touches went straight to HBM: drain what was staged before
+            const uint32_t upto = big ? s_old : (s_now & ~31u);
+            flush_range(L, tin, s_sl, read_lane(my_flushed, s_sl), upto);
+            if (lane == s_sl) my_flushed = big ? s_now : upto;
+        }
+        if (stamp) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_close += t1 - t0; }
+        if (r < hi) posP[r] = pos;
+    };
+    const unsigned long long t_setup = __builtin_amdgcn_s_memtime() - t_begin;
+    // The walk is serial in the chain offsets, so the event loads must not be.  On this ISA loads
+    // and stores share one in-flight counter and complete out of order with respect to each
+    // other, so consuming ANY load while stores are in flight drains them all (~1 us): the events
+    // are therefore fetched sixteen 64-event rows at a time, one group ahead (clamped, never
+    // branched-over addresses), and the drain is paid once per 1024 events instead of per row.
+    if (lo < hi) {
+        constexpr int kRows = 16;
+        uint32_t cur[kRows], nxt[kRows];
+        auto fetch = [&](uint32_t base, uint32_t (&rows)[kRows]) {
+#pragma unroll
+            for (int k = 0; k < kRows; k++) rows[k] = events[min(base + 64u * uint32_t(k) + uint32_t(lane), hi - 1)];
+        };
+        fetch(lo, cur);
+        for (uint32_t base = lo; base < hi; base += 64u * kRows) {
+            fetch(base + 64u * kRows, nxt);
+#pragma unroll 1
+            for (int k = 0; k < kRows && base + 64u * uint32_t(k) < hi; k++) place(base + 64u * uint32_t(k), cur[k]);
+#pragma unroll
+            for (int k = 0; k < kRows; k++) cur[k] = nxt[k];
+        }
+    }
+    for (int sl = 0; sl < kStageSlots; sl++) {                  // what is left in the rings
+        const uint32_t key = read_lane(my_key, sl);
+        if (key != 0xFFFFu) flush_range(L, tin, sl, read_lane(my_flushed, sl), L.off[key]);
+    }
+    if (stamp && lane == 0 && (seg & 63) == 0) {
+        const auto d = gptr(J.b.dbg_out) + 2048 + (parity * 4 + (seg >> 6)) * 8;
+        d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_setup; d[2] = t_match; d[3] = t_place; d[4] = t_close; d[5] = hi - lo;
     }
 }
 
@@ -875,13 +1003,18 @@ __global__ void __launch_bounds__(256) k_counter_probs(const E1Job *__restrict__
 __global__ void __launch_bounds__(256) k_mix(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
     const auto events = gptr(J.b.events); const auto tout = gptr(J.b.tout);
-    const auto tpos = (NB_GLOBAL const u32x2 *)gptr(J.b.tpos); const auto coded = gptr(J.b.coded);
+    const auto pos0 = (NB_GLOBAL const uint32_t *)gptr(J.b.tpos); const auto coded = gptr(J.b.coded);
+    const auto pos1 = pos0 + ((size_t(J.n_ev) + 63) & ~size_t(63));
     uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= J.n_ev) return;
     uint32_t e = events[r];
-    u32x2 tp = tpos[r];
+    // k_touch_scatter files positions by tree PARITY; tree u is the one with qu's parity, and an
+    // event without a second touch (both trees equal, or weight 0) mixes its one P with itself
+    const uint32_t p0 = pos0[r], p1 = pos1[r];
+    const bool odd = (ev_qu(e) & 1) != 0;
+    const uint32_t at_u = odd ? p1 : p0, other = odd ? p0 : p1, at_v = other == kNoTouch ? at_u : other;
     int qw = ev_qw(e);
-    int pu = tout[tp.x], pv = tout[tp.y];
+    int pu = tout[at_u], pv = tout[at_v];
     coded[r] = pack_coded(mix_prob(pu, pv, qw), ev_bin(e));
 }
 
@@ -1100,7 +1233,7 @@ void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
     mark(); hipLaunchKernelGGL(k_emit_bins, dim3(cdiv(max_n, 256), n_jobs), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_touch_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<3>(d_jobs, n_jobs, 4096u * max_nseg, s, mark);
-    mark(); hipLaunchKernelGGL(k_touch_scatter, seg_grid, dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_touch_scatter, dim3(seg_grid.x, seg_grid.y, 2), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_plan_windows, dim3(1, n_jobs), dim3(1024), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_counter_epochs, dim3(4096, n_jobs), dim3(64), 0, s, d_jobs);
     const unsigned max_windows = unsigned(2ull * max_ev / kWin) + 4096u;          // every touch list has <= 2 touches per bin

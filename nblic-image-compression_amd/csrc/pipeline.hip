@@ -235,7 +235,7 @@ static void group_free(Group &g) {
 static bool ensure_events(Slot &s, size_t n_ev) {
     if (n_ev <= s.ev_cap) return true;
     size_t cap = n_ev + n_ev / 8 + 1024;
-    if (!dev_alloc(s.b.events, cap) || !dev_alloc(s.b.tin, 2 * cap + kStreamPad) || !dev_alloc(s.b.tpos, cap) ||
+    if (!dev_alloc(s.b.events, cap) || !dev_alloc(s.b.tin, 2 * cap + kStreamPad) || !dev_alloc(s.b.tpos, cap + 64) ||
         !dev_alloc(s.b.tout, 2 * cap + kStreamPad) ||
         !dev_alloc(s.b.win_recs, (2 * cap / 512 + 4096 + 8) * 24)) return false;
     s.ev_cap = cap;
