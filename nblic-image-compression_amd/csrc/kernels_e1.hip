@@ -262,9 +262,13 @@ __global__ void __launch_bounds__(256) k_adr_count(const E1Job *__restrict__ job
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<M::kKeys>(hist, 0);
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
-    for (uint32_t base = lo; base < hi; base += 64) {
-        uint32_t t = base + lane_id();
-        if (t < hi) atomicAdd(&hist[M::key(rec1[t])], 1u);
+    for (uint32_t base = lo; base < hi; base += 512) {            // eight rows of loads in flight (see k_touch_count)
+        uint32_t r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = rec1[min(base + 64u * uint32_t(k) + uint32_t(lane_id()), hi - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (base + 64u * uint32_t(k) + uint32_t(lane_id()) < hi) atomicAdd(&hist[M::key(r[k])], 1u);
     }
     for (int k = lane_id(); k < M::kKeys; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
 }
@@ -583,13 +587,19 @@ __global__ void __launch_bounds__(256) k_touch_count(const E1Job *__restrict__ j
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<4096>(hist, 0);
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n_ev, lo + plan.seg_len);
-    for (uint32_t base = lo; base < hi; base += 64) {
-        uint32_t r = base + lane_id();
-        if (r < hi) {
-            uint32_t e = events[r];
-            Touch a = touch_of(e, 0), b = touch_of(e, 1);
-            if (a.valid) atomicAdd(&hist[a.key], 1u);
-            if (b.valid) atomicAdd(&hist[b.key], 1u);
+    // eight rows of loads in flight per wave (clamped addresses, no branch around a load): the
+    // histogram updates are LDS atomics, so nothing but the load latency paces this loop
+    for (uint32_t base = lo; base < hi; base += 512) {
+        uint32_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = events[min(base + 64u * uint32_t(k) + uint32_t(lane_id()), hi - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (base + 64u * uint32_t(k) + uint32_t(lane_id()) < hi) {
+                Touch a = touch_of(e[k], 0), b = touch_of(e[k], 1);
+                if (a.valid) atomicAdd(&hist[a.key], 1u);
+                if (b.valid) atomicAdd(&hist[b.key], 1u);
+            }
         }
     }
     for (int k = lane_id(); k < 4096; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
