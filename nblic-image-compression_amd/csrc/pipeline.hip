@@ -344,17 +344,20 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
 
 // Coder thread.  Measured on the GPU box (EPYC 9575F), per thread: one stream alone 400-510
 // Mbins/s; packs always run as two AVX-512 registers in lock-step: 2 x 4 images 1300 Mbins/s,
-// 2 x 8 images 1875 Mbins/s -- at 2.5x / 3.4x the latency of a stream coded alone.  The host's
-// CPU share, not the GPU, bounds the pipeline, so a thread takes everything that is queued (up to
-// sixteen) as one pack; only when no more images are left than there are threads -- a short
-// batch, or the very tail of a long one -- does each image go to a thread of its own.  (Policy
-// picked with a discrete-event model of arrivals and coder speeds, tools/coder_policy_sim.py.)
+// 2 x 8 images 1950 Mbins/s -- at 2.5x / 3.4x the latency of a stream coded alone.  The host's
+// CPU share (16 cores, enforced as a quota), not the GPU, bounds the pipeline, so what counts is
+// bins per CPU-second: mid-batch a thread waits the ~30 ms it takes for sixteen images to be
+// queued rather than start a smaller pack; towards the end it takes whatever is there; and only
+// when no more images are left than there are threads -- a short batch, or the very tail of a
+// long one -- does each image go to a thread of its own.  (Alternatives ranked with a
+// discrete-event model of arrivals and coder speeds, tools/coder_policy_sim.py, then in situ.)
 static int coder_take(const nblic_amd_ctx *c) {                  // call with c->rm held; 0 = nothing to take
     const size_t q = c->ready.size();
     if (q == 0) return 0;
     if (c->ready.front().kind != 0 || !c->simd) return 1;
     const size_t left = q + size_t(c->batch_to_come), threads = c->coders.size();
     if (left <= threads) return 1;
+    if (q < size_t(kMaxTake) && c->batch_to_come > 0 && left >= 4 * threads) return 0;   // mid-batch: wait (~30 ms) for a full pack
     return int(q < size_t(kMaxTake) ? q : size_t(kMaxTake));
 }
 
@@ -367,9 +370,10 @@ static void coder_main(nblic_amd_ctx *c, int index) {
         {
             std::unique_lock<std::mutex> l(c->rm);
             c->idle_coders++;
-            c->rcv.wait(l, [c] { return c->stop || !c->ready.empty(); });
+            c->rcv.wait(l, [c] { return c->stop || coder_take(c) > 0; });
             if (c->ready.empty()) break;
             take = coder_take(c);
+            if (take == 0) break;                                // shutdown while waiting for a pack to fill
             c->idle_coders--;
             for (int k = 0; k < take; k++) {
                 if (k > 0 && c->ready.front().kind != 0) { take = k; break; }
