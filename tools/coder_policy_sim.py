@@ -5,7 +5,13 @@ The GPU delivers groups of 8 images every ~29 ms after a ~100 ms ramp; a coder t
 images together in T(k) seconds (measured on the GPU box's EPYC 9575F: scalar 450 Mbins/s,
 8 AVX-512 lanes ~137 Mbins/s per lane, 16 lanes ~91 Mbins/s per lane; 74.5 Mbins per 4096x4096
 SYN-1 frame).  Prints the whole-batch Mpixel/s each policy would reach for several batch sizes.
-No GPU needed."""
+No GPU needed.
+
+What the model does NOT capture, and the in-situ runs showed: the host share is a hard 16-CPU
+quota, so once every thread is busy the pipeline is paced by bins per CPU-second, not by per-thread
+speed.  Measured at 512 frames per step: greedy packs 3257 Mpixel/s; waiting mid-batch for full
+16-image packs 3382; an even-share drain from half-way through the batch 2976 (too many small,
+inefficient packs).  pipeline.hip ships the second."""
 import heapq
 
 BINS = 74.5e6
