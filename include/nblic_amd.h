@@ -137,6 +137,13 @@ void nblic_amd_syn1(unsigned char *img, int height, int width, uint32_t seed);
 int nblic_amd_range_code_multi(const uint16_t *const *coded, const size_t *n, int count, unsigned char *const *outs,
                                const size_t *caps, size_t *lens);
 
+/* The same streams fed `chunk` bins at a time through the RESUMABLE coders, exactly as the coder
+ * threads do when they stream an image's bins from HBM (one stream: scalar coder; more: two
+ * AVX-512 packs in lock-step, up to 16 streams).  Host function; exists so that the chunked path
+ * can be checked without a GPU.  Returns 0, or -1 for count outside 1..16 or chunk == 0.        */
+int nblic_amd_range_code_chunked(const uint16_t *const *coded, const size_t *n, int count, unsigned char *const *outs,
+                                 const size_t *caps, size_t *lens, size_t chunk);
+
 const char *nblic_amd_version(void);
 
 #ifdef __cplusplus

@@ -37,7 +37,7 @@ EXPORTS = (
     "NBLICcompress", "NBLICdecompress", "QNBLICcompress", "QNBLICdecompress", "QNBLICcompressMultiThread",
     "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_qencode_batch", "nblic_amd_set_max_pixels",
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
-    "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
+    "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_range_code_chunked", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
 )
 
 
@@ -102,6 +102,9 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_range_code_multi.restype = C.c_int
     lib.nblic_amd_range_code_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p),
                                                C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.nblic_amd_range_code_chunked.restype = C.c_int
+    lib.nblic_amd_range_code_chunked.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t]
     lib.nblic_amd_selftest.restype = C.c_int
     lib.nblic_amd_selftest.argtypes = [C.c_void_p]
     lib.nblic_amd_syn1.restype = None
@@ -210,6 +213,25 @@ def range_code_multi(streams: Sequence[np.ndarray], caps: Optional[Sequence[int]
     simd = lib.nblic_amd_range_code_multi(cp, nn, k, op, cc, ln)
     bad = C.c_size_t(-1).value
     return [None if ln[i] == bad else outs[i][: ln[i]].tobytes() for i in range(k)], simd
+
+
+def range_code_chunked(streams: Sequence[np.ndarray], chunk: int, caps: Optional[Sequence[int]] = None):
+    """Up to 16 bin streams fed ``chunk`` bins at a time through the resumable coders
+    (``nblic_amd_range_code_chunked``) -- the coder threads' path, minus the GPU."""
+    lib = load_library()
+    arrs = [np.ascontiguousarray(a, np.uint16) for a in streams]
+    k = len(arrs)
+    caps = [a.size * 4 + 16 for a in arrs] if caps is None else list(caps)
+    outs = [np.empty(max(c, 1), np.uint8) for c in caps]
+    cp = (C.c_void_p * k)(*[C.c_void_p(a.ctypes.data) for a in arrs])
+    nn = (C.c_size_t * k)(*[a.size for a in arrs])
+    op = (C.c_void_p * k)(*[C.c_void_p(o.ctypes.data) for o in outs])
+    cc = (C.c_size_t * k)(*caps)
+    ln = (C.c_size_t * k)()
+    if lib.nblic_amd_range_code_chunked(cp, nn, k, op, cc, ln, C.c_size_t(chunk)) != 0:
+        raise ValueError("nblic_amd_range_code_chunked: 1..16 streams, chunk > 0")
+    bad = C.c_size_t(-1).value
+    return [None if ln[i] == bad else outs[i][: ln[i]].tobytes() for i in range(k)]
 
 
 # ---------------------------------------------------------------------------------------------

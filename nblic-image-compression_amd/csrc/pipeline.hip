@@ -696,6 +696,35 @@ int nblic_amd_range_code_multi(const uint16_t *const *coded, const size_t *n, in
     return 0;
 }
 
+int nblic_amd_range_code_chunked(const uint16_t *const *coded, const size_t *n, int count, unsigned char *const *outs,
+                                 const size_t *caps, size_t *lens, size_t chunk) {
+    if (count < 1 || count > kMaxTake || chunk == 0) return -1;
+    size_t n_max = 0;
+    for (int k = 0; k < count; k++) n_max = n[k] > n_max ? n[k] : n_max;
+    const bool packs = count > 1 && have_avx512();
+    if (!packs) {                                              // one after the other through the scalar coder
+        for (int k = 0; k < count; k++) {
+            RangeScalar r;
+            r.begin(outs[k], caps[k]);
+            for (size_t off = 0; off < n[k]; off += chunk) r.feed(coded[k] + off, n[k] - off < chunk ? n[k] - off : chunk);
+            lens[k] = r.finish();
+        }
+        return 0;
+    }
+    RangeX8 a, b;
+    const int na = (count + 1) / 2;
+    a.begin(na, outs, caps);
+    b.begin(count - na, outs + na, caps + na);
+    for (size_t off = 0; off < n_max; off += chunk) {
+        const uint16_t *src[kMaxTake + 8] = {nullptr}; size_t len[kMaxTake + 8] = {0};
+        for (int k = 0; k < count; k++) { src[k] = coded[k] + off; len[k] = off >= n[k] ? 0 : (n[k] - off < chunk ? n[k] - off : chunk); }
+        feed_pair(a, src, len, b, src + na, len + na);
+    }
+    a.end(lens);
+    b.end(lens + na);
+    return 0;
+}
+
 int nblic_amd_selftest(nblic_amd_ctx *c) {
     if (!c || hipSetDevice(c->device) != hipSuccess) return -1;
     return e1_selftest(c->groups[0].stream);
