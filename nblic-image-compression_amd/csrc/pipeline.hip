@@ -252,7 +252,7 @@ static bool ensure_pixels(Slot &s, size_t n, bool with_events = true) {
             !dev_alloc(s.b.blk_ok, cap / 4096 + 4096 + 64)) return false;
         s.px_cap = cap;
     }
-    return with_events ? ensure_events(s, 6 * n) : true;   // typical images need 4.3-4.5 bins/px; grown on demand
+    return with_events ? ensure_events(s, 5 * n) : true;   // typical images need 4.3-4.5 bins/px (ensure_events adds 1/8); grown on demand
 }
 
 // Front half for the images assigned to group g (slots 0..n_jobs-1 already carry job/h/w).
