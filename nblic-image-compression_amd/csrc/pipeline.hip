@@ -157,6 +157,9 @@ struct nblic_amd_ctx {
     std::mutex fm;                        // free groups / free host buffers / outstanding work
     std::condition_variable fcv;
     std::deque<int> free_groups;
+    bool trace = false;                      // NBLIC_AMD_DBG & 64: timeline of groups and coder takes on stderr
+    std::chrono::steady_clock::time_point t_batch;
+    double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_batch).count(); }
     std::vector<hipStream_t> copy_streams;   // shared by the coder threads (device -> host chunk copies)
     std::vector<CodedBuf> cbufs;
     std::deque<int> free_cbufs;
@@ -346,8 +349,10 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
 // Mbins/s; packs always run as two AVX-512 registers in lock-step: 2 x 4 images 1300 Mbins/s,
 // 2 x 8 images 1950 Mbins/s -- at 2.5x / 3.4x the latency of a stream coded alone.  The host's
 // CPU share (16 cores, enforced as a quota), not the GPU, bounds the pipeline, so what counts is
-// bins per CPU-second: mid-batch a thread waits the ~30 ms it takes for sixteen images to be
-// queued rather than start a smaller pack; towards the end it takes whatever is there; and only
+// bins per CPU-second: mid-batch, once every other thread is busy, a thread waits the ~30 ms it
+// takes for sixteen images to be queued rather than start a smaller pack (while others are idle --
+// the start of a batch -- it takes what is there, so all threads are at work within 0.4 s);
+// towards the end it takes whatever is there; and only
 // when no more images are left than there are threads -- a short batch, or the very tail of a
 // long one -- does each image go to a thread of its own.  (Alternatives ranked with a
 // discrete-event model of arrivals and coder speeds, tools/coder_policy_sim.py, then in situ.)
@@ -357,7 +362,7 @@ static int coder_take(const nblic_amd_ctx *c) {                  // call with c-
     if (c->ready.front().kind != 0 || !c->simd) return 1;
     const size_t left = q + size_t(c->batch_to_come), threads = c->coders.size();
     if (left <= threads) return 1;
-    if (q < size_t(kMaxTake) && c->batch_to_come > 0 && left >= 4 * threads) return 0;   // mid-batch: wait (~30 ms) for a full pack
+    if (q < size_t(kMaxTake) && c->batch_to_come > 0 && left >= 4 * threads && c->idle_coders <= 1) return 0;   // mid-batch, every other thread busy: wait (~30 ms) for a full pack
     return int(q < size_t(kMaxTake) ? q : size_t(kMaxTake));
 }
 
@@ -406,6 +411,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
             continue;
         }
         auto t0 = std::chrono::steady_clock::now();
+        if (c->trace) fprintf(stderr, "[trace] %.3f coder %d takes %d\n", c->now(), index, take);
         const uint16_t *src[kMaxTake]; size_t n[kMaxTake], caps[kMaxTake], lens[kMaxTake]; uint8_t *dst[kMaxTake];
         double bins = 0;
         for (int k = 0; k < take; k++) {
@@ -427,6 +433,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
             im[k].lens[im[k].job] = lens[k] == SIZE_MAX ? -1 : long(kHeaderBytes + lens[k]);
         }
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (c->trace) fprintf(stderr, "[trace] %.3f coder %d finished %d in %.3f s\n", c->now(), index, take, dt);
         { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; if (take > 1) { c->pack_bins += bins; c->pack_s += dt; } c->wait_s += t.wait_s; t.wait_s = 0; c->takes[take]++; }
         {
             std::lock_guard<std::mutex> l(c->fm);
@@ -462,6 +469,7 @@ static bool acquire_coded(nblic_amd_ctx *c, Slot &s, size_t words) {
 static void on_group_done(void *vp) {
     Group *gp = static_cast<Group *>(vp);
     nblic_amd_ctx *c = gp->ctx;
+    if (c->trace) fprintf(stderr, "[trace] %.3f group %d done (%d images)\n", c->now(), gp->id, gp->n_jobs);
     {
         std::lock_guard<std::mutex> l(c->rm);
         for (int k = 0; k < gp->n_jobs; k++) {
@@ -556,6 +564,8 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
     c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; for (auto &v : c->takes) v = 0;
     bool ok = true;
     c->failed = false;
+    c->t_batch = std::chrono::steady_clock::now();
+    c->trace = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 64);
     for (int k = 0; k < n_images; k++) lens[k] = -1;
     { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come = n_images; }
     int next = 0;
