@@ -7,13 +7,14 @@
 //
 //   k_predict            S1  stateless, one lane per pixel        -> rec1[t]
 //   partition by adr     (count -> scan -> scatter)               -> s2in[]  grouped by context, pos2[t]
-//   k_bias_chains        S2  one LANE per context chain           -> s2out[] (px | sign<<8, same order)
+//   k_bias_blocks/_fixup S2  one LANE per 4096-record block of a context chain (monotone coupling) -> s2out[] (state >> 7)
 //   partition by px|sign (gathers s2out through pos2)             -> s3in[]  grouped by re-mapper, pos3[t]
-//   k_mapper_chains      S3  one LANE per re-mapper chain, state in LDS -> s3out[] (z, same order)
+//   k_mapper_chains      S3  one LANE per re-mapper chain (16 per wave), counts in LDS -> s3out[] (z, same order)
 //   k_count_bins/k_emit_bins  S4 stateless (gathers z through pos3)     -> events[r]
-//   partition by counter (even / odd trees)                       -> tin[]  grouped by counter, tpos[2r+slot]
-//   k_counter_chains     S5  one WAVE per counter chain (scan within a halving epoch) -> tout[] (P, same order)
-//   k_mix                gathers the two P through tpos, mixes, packs -> coded[r] (u16) for the host coder
+//   partition by counter (even / odd trees; hot chains staged in LDS) -> tin[] grouped by counter, two position arrays
+//   k_counter_epochs     S5a one WAVE per counter chain: resolves the halvings        -> win_recs[]
+//   k_counter_probs      S5b one WAVE per 512-touch window: P before every touch      -> tout[] (same order as tin)
+//   k_mix                gathers the two P through the position arrays, mixes, packs  -> coded[r] (u16) for the host coder
 //
 // The chain kernels are the serial part, so they touch memory only as dense streams of 2-byte
 // records in key-sorted order: every global request of a chain kernel is one coalesced 512-byte
@@ -486,6 +487,7 @@ __device__ __forceinline__ void perm_set(Perm20 &p, int i, int v) {
     if (up) p.hi = w; else p.lo = w;
 }
 
+constexpr int kMapLanes = 16;
 __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ jobs) {
     __shared__ int count[kMapSyms][64];
     __shared__ u32x2 stage[64 * kRowWords];
@@ -494,14 +496,17 @@ __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ 
     const auto total = gptr(J.b.totals) + 1; const auto map_state = gptr(J.b.map_state);
     const auto s3out = gptr(J.b.s3out); const SegPlan plan = J.pp;
     const int lane = int(threadIdx.x);
-    const int key = int(blockIdx.x) * 64 + lane;
+    // Only kMapLanes lanes of the wave carry a chain: the walk is in lockstep, and the rare swap
+    // branch is taken by SOME lane on 73 % of the steps with 64 chains, on 28 % with 16.
+    const bool active = lane < kMapLanes;
+    const int key = int(blockIdx.x) * kMapLanes + (active ? lane : 0);
     auto st = map_state + size_t(key) * (3 * kMapSyms);
     Perm20 rank_of{0, 0}, sym_at{0, 0};
     for (int k = 0; k < kMapSyms; k++) {
         perm_set(rank_of, k, st[k]); perm_set(sym_at, k, st[kMapSyms + k]); count[k][lane] = st[2 * kMapSyms + k];
     }
-    const uint32_t start = table[size_t(key) * plan.nseg];
-    const uint32_t end = key + 1 < 512 ? table[size_t(key + 1) * plan.nseg] : *total;
+    const uint32_t start = active ? table[size_t(key) * plan.nseg] : 0u;
+    const uint32_t end = !active ? 0u : (key + 1 < 512 ? table[size_t(key + 1) * plan.nseg] : *total);
     run_lane_streams(s3in, s3out, start, end, start, stage, [&](uint32_t y, uint32_t) {
         const int zz = perm_get(rank_of, int(y));
         const int up = zz > 0 ? zz - 1 : 0;
@@ -515,9 +520,10 @@ __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ 
         }
         return uint32_t(zz);
     }, (J.dbg & 8) ? gptr(J.b.dbg_out) + 64 + blockIdx.x * 4 : nullptr);
-    for (int k = 0; k < kMapSyms; k++) {
-        st[k] = perm_get(rank_of, k); st[kMapSyms + k] = perm_get(sym_at, k); st[2 * kMapSyms + k] = count[k][lane];
-    }
+    if (active)
+        for (int k = 0; k < kMapSyms; k++) {
+            st[k] = perm_get(rank_of, k); st[kMapSyms + k] = perm_get(sym_at, k); st[2 * kMapSyms + k] = count[k][lane];
+        }
 }
 
 // ---- S4: binarisation (NBLIC.c:640-679); path depends on (qu,qv,qw,z) only ----------------
@@ -1225,7 +1231,7 @@ void e1_launch_front(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipSt
     mark(); hipLaunchKernelGGL(k_map_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<1>(d_jobs, n_jobs, 512u * max_nseg, s, mark);
     mark(); hipLaunchKernelGGL(k_map_scatter, seg_grid, dim3(256), 0, s, d_jobs);
-    mark(); hipLaunchKernelGGL(k_mapper_chains, dim3(512 / 64, n_jobs), dim3(64), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_mapper_chains, dim3(512 / kMapLanes, n_jobs), dim3(64), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_count_bins, px_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<2>(d_jobs, n_jobs, max_n, s, mark);
     mark();                                                     // start of the host gap (index 20)
