@@ -295,6 +295,23 @@ class Context:
         outs, lens = self.encode_ptrs([p.ctypes.data for p in planes], [p.shape for p in planes], False)
         return [o[:int(n)].tobytes() for o, n in zip(outs, lens)]
 
+    def qencode_ptrs(self, ptrs: Sequence[int], shapes: Sequence[Tuple[int, int]], on_device: bool,
+                     outs: Optional[List[np.ndarray]] = None) -> Tuple[List[np.ndarray], np.ndarray]:
+        """Effort-0 (QNBLIC) encode of planes given as raw addresses (host or device).  Returns
+        (uint16 out buffers, lengths in 16-bit words)."""
+        k = len(ptrs)
+        if outs is None:
+            outs = [np.empty(out_capacity(h, w) // 2, np.uint16) for (h, w) in shapes]
+        ip_ = (C.c_void_p * k)(*[C.c_void_p(int(p)) for p in ptrs])
+        hs = (C.c_int * k)(*[int(s[0]) for s in shapes])
+        ws = (C.c_int * k)(*[int(s[1]) for s in shapes])
+        op = (C.c_void_p * k)(*[C.c_void_p(o.ctypes.data) for o in outs])
+        caps = (C.c_size_t * k)(*[o.size for o in outs])
+        lens = (C.c_long * k)()
+        if self.lib.nblic_amd_qencode_batch(self.handle, k, ip_, int(on_device), hs, ws, op, caps, lens) != 0:
+            raise RuntimeError(f"nblic_amd_qencode_batch failed (lengths {list(lens)})")
+        return outs, np.array(lens[:], np.int64)
+
     def qencode_batch(self, imgs: Sequence[np.ndarray]) -> List[bytes]:
         """Effort-0 (QNBLIC) encode of host planes; returns the streams as bytes (little-endian words)."""
         planes = [np.ascontiguousarray(i, np.uint8) for i in imgs]

@@ -353,15 +353,15 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
 // takes for sixteen images to be queued rather than start a smaller pack (while others are idle --
 // the start of a batch -- it takes what is there, so all threads are at work within 0.4 s);
 // towards the end it takes whatever is there; and only
-// when no more images are left than there are threads -- a short batch, or the very tail of a
-// long one -- does each image go to a thread of its own.  (Alternatives ranked with a
+// when at most two images per thread are left -- a short batch, or the very tail of a long one --
+// does each image go to a thread of its own.  (Alternatives ranked with a
 // discrete-event model of arrivals and coder speeds, tools/coder_policy_sim.py, then in situ.)
 static int coder_take(const nblic_amd_ctx *c) {                  // call with c->rm held; 0 = nothing to take
     const size_t q = c->ready.size();
     if (q == 0) return 0;
     if (c->ready.front().kind != 0 || !c->simd) return 1;
     const size_t left = q + size_t(c->batch_to_come), threads = c->coders.size();
-    if (left <= threads) return 1;
+    if (left <= 2 * threads) return 1;                           // two rounds of singles beat one small pack
     if (q < size_t(kMaxTake) && c->batch_to_come > 0 && left >= 4 * threads && c->idle_coders <= 1) return 0;   // mid-batch, every other thread busy: wait (~30 ms) for a full pack
     return int(q < size_t(kMaxTake) ? q : size_t(kMaxTake));
 }

@@ -36,6 +36,17 @@ if ref:
     _, t = timed(lambda: ref.encode(frames[0], 0, 1))
     out["e1_reference_cpu_Mpx_s"] = round(H * W / t / 1e6, 2)
 ctx.close()
+# effort 0 with the frames resident in HBM, a batch large enough to fill the pipeline
+ctx = pkg.Context(device=0, n_slots=48, n_coders=16, n_groups=6, n_host_buffers=128)
+dev = [torch.from_numpy(f).to("cuda:0") for f in frames] * 8                     # 256 planes (32 distinct)
+torch.cuda.synchronize()
+outs = [np.empty((H * W + 8192) // 2, np.uint16) for _ in dev]
+shapes = [(H, W)] * len(dev)
+ctx.qencode_ptrs([d.data_ptr() for d in dev], shapes, True, outs)
+(_, lens_q), t = timed(lambda: ctx.qencode_ptrs([d.data_ptr() for d in dev], shapes, True, outs), 2)
+out["e0_device_inputs_256x4096_Mpx_s"] = round(len(dev) * H * W / t / 1e6, 1)
+assert outs[0][: int(lens_q[0])].tobytes() == pkg.qcompress(frames[0])
+ctx.close()
 # raster-serial engine (one lane) vs the CPU oracle on small frames
 for name, (h, w, near, effort) in {"e1_n2_256": (256, 256, 2, 1), "e2_n0_96": (96, 96, 0, 2), "e3_n0_64": (64, 64, 0, 3)}.items():
     img = pkg.syn1(h, w, 1)
