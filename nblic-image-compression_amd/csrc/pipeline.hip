@@ -538,6 +538,13 @@ static void driver_main(nblic_amd_ctx *c, int id) {
         if (!ok) {
             c->failed = true;
             hipStreamSynchronize(g.stream);
+            {   // coded-bin buffers the failed launch had already taken go back to the pool
+                std::lock_guard<std::mutex> l(c->fm);
+                for (int k = 0; k < g.n_jobs; k++) {
+                    Slot &s = g.slots[size_t(k)];
+                    if (s.cb >= 0) { c->free_cbufs.push_back(s.cb); s.cb = -1; }
+                }
+            }
             { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come -= g.n_jobs; }
             c->rcv.notify_all();                                 // a pack may be waiting for images that will not come
             { std::lock_guard<std::mutex> l(c->fm); c->coding -= g.n_jobs; }
@@ -584,7 +591,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
             int k = next++;
             if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; std::lock_guard<std::mutex> l(c->rm); c->batch_to_come--; continue; }
             Slot &s = g.slots[size_t(g.n_jobs++)];
-            s.job = k; s.h = hs[k]; s.w = ws[k];
+            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1;
         }
         if (g.n_jobs == 0) { release_group(c, id); continue; }
         start_group(c, g, imgs, on_device);
@@ -658,7 +665,7 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
             int k = next++;
             if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; std::lock_guard<std::mutex> l(c->rm); c->batch_to_come--; continue; }
             Slot &s = g.slots[size_t(g.n_jobs++)];
-            s.job = k; s.h = hs[k]; s.w = ws[k];
+            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1;
         }
         if (g.n_jobs == 0) { release_group(c, id); continue; }
         start_group(c, g, imgs, on_device);
