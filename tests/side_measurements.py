@@ -3,7 +3,7 @@
 image latency, PCIe-inclusive rate, and the raster-serial engine against the CPU oracle."""
 import importlib, json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import torch
 torch.cuda.init()
 pkg = importlib.import_module("nblic-image-compression_amd")
