@@ -286,19 +286,38 @@ __global__ void __launch_bounds__(256) k_adr_scatter(const E1Job *__restrict__ j
     uint32_t *off = lds[threadIdx.x >> 6];
     for (int k = lane_id(); k < M::kKeys; k += 64) off[k] = table[size_t(k) * plan.nseg + seg];
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
-    for (uint32_t base = lo; base < hi; base += 64) {
-        uint32_t t = base + lane_id();
-        bool valid = t < hi;
-        uint32_t r = valid ? rec1[t] : 0u;
-        uint32_t key = M::key(r);
-        uint64_t same = match_lanes<M::kKeyBits>(key, valid);
-        if (valid) {
-            uint32_t rank = __popcll(same & lanes_below());
-            uint32_t pos = off[key] + rank;
-            s2in[pos] = M::err_rec(int(x[t]), r);
-            pos2[t] = pos;
-            if (rank == 0) off[key] += uint32_t(__popcll(same));
+    // rows are fetched eight at a time, one group ahead, with clamped addresses (see k_touch_scatter:
+    // a load consumed while stores are in flight drains them all, so the drain is paid per group)
+    if (lo >= hi) return;
+    constexpr int kRows = 8;
+    uint32_t cur_r[kRows], nxt_r[kRows], cur_x[kRows], nxt_x[kRows];
+    auto fetch = [&](uint32_t base, uint32_t (&rr)[kRows], uint32_t (&xx)[kRows]) {
+#pragma unroll
+        for (int k = 0; k < kRows; k++) {
+            const uint32_t t = min(base + 64u * uint32_t(k) + uint32_t(lane_id()), hi - 1);
+            rr[k] = rec1[t]; xx[k] = x[t];
         }
+    };
+    fetch(lo, cur_r, cur_x);
+    for (uint32_t gbase = lo; gbase < hi; gbase += 64u * kRows) {
+        fetch(gbase + 64u * kRows, nxt_r, nxt_x);
+#pragma unroll 1
+        for (int k = 0; k < kRows && gbase + 64u * uint32_t(k) < hi; k++) {
+            const uint32_t t = gbase + 64u * uint32_t(k) + uint32_t(lane_id());
+            const bool valid = t < hi;
+            const uint32_t r = cur_r[k];
+            const uint32_t key = M::key(r);
+            const uint64_t same = match_lanes<M::kKeyBits>(key, valid);
+            if (valid) {
+                const uint32_t rank = __popcll(same & lanes_below());
+                const uint32_t pos = off[key] + rank;
+                s2in[pos] = M::err_rec(int(cur_x[k]), r);
+                pos2[t] = pos;
+                if (rank == 0) off[key] += uint32_t(__popcll(same));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRows; k++) { cur_r[k] = nxt_r[k]; cur_x[k] = nxt_x[k]; }
     }
 }
 
@@ -453,19 +472,37 @@ __global__ void __launch_bounds__(256) k_map_scatter(const E1Job *__restrict__ j
     uint32_t *off = lds[threadIdx.x >> 6];
     for (int k = lane_id(); k < 512; k += 64) off[k] = table[size_t(k) * plan.nseg + seg];
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
-    for (uint32_t base = lo; base < hi; base += 64) {
-        uint32_t t = base + lane_id(), key = 0; int y = 0;
-        bool in = t < hi;
-        bool valid = in && mapper_item(int(x[t]), pxs[t], key, y);
-        if (in && !valid) pos3[t] = 0x80000000u | uint32_t(y);    // y >= 20 codes as itself (NBLIC.c:488)
-        uint64_t same = match_lanes<9>(key, valid);
-        if (valid) {
-            uint32_t rank = __popcll(same & lanes_below());
-            uint32_t pos = off[key] + rank;
-            s3in[pos] = uint16_t(y);
-            pos3[t] = pos;
-            if (rank == 0) off[key] += uint32_t(__popcll(same));
+    if (lo >= hi) return;
+    constexpr int kRows = 8;                                       // eight rows per group, one group ahead (see k_adr_scatter)
+    uint32_t cur_p[kRows], nxt_p[kRows], cur_x[kRows], nxt_x[kRows];
+    auto fetch = [&](uint32_t base, uint32_t (&pp)[kRows], uint32_t (&xx)[kRows]) {
+#pragma unroll
+        for (int k = 0; k < kRows; k++) {
+            const uint32_t t = min(base + 64u * uint32_t(k) + uint32_t(lane_id()), hi - 1);
+            pp[k] = pxs[t]; xx[k] = x[t];
         }
+    };
+    fetch(lo, cur_p, cur_x);
+    for (uint32_t gbase = lo; gbase < hi; gbase += 64u * kRows) {
+        fetch(gbase + 64u * kRows, nxt_p, nxt_x);
+#pragma unroll 1
+        for (int k = 0; k < kRows && gbase + 64u * uint32_t(k) < hi; k++) {
+            const uint32_t t = gbase + 64u * uint32_t(k) + uint32_t(lane_id());
+            uint32_t key = 0; int y = 0;
+            const bool in = t < hi;
+            const bool valid = mapper_item(int(cur_x[k]), cur_p[k], key, y) && in;
+            if (in && !valid) pos3[t] = 0x80000000u | uint32_t(y);    // y >= 20 codes as itself (NBLIC.c:488)
+            const uint64_t same = match_lanes<9>(key, valid);
+            if (valid) {
+                const uint32_t rank = __popcll(same & lanes_below());
+                const uint32_t pos = off[key] + rank;
+                s3in[pos] = uint16_t(y);
+                pos3[t] = pos;
+                if (rank == 0) off[key] += uint32_t(__popcll(same));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRows; k++) { cur_p[k] = nxt_p[k]; cur_x[k] = nxt_x[k]; }
     }
 }
 
