@@ -447,14 +447,39 @@ __global__ void __launch_bounds__(256) k_map_count(const E1Job *__restrict__ job
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<512>(hist, 0);
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
-    for (uint32_t base = lo; base < hi; base += 64) {
-        uint32_t t = base + lane_id(), key; int y;
-        if (t < hi) {
-            int vs = int(int16_t(s2out[pos2[t]]));                     // context state >> 7 as the chain saw it
-            int sign = vs & 1;
-            uint16_t ps = uint16_t(iclip(s1_px0(rec1[t]) + (vs >> 1) + sign, 0, kMaxVal) | (sign << 8));
-            pxs[t] = ps;
-            if (mapper_item(int(x[t]), ps, key, y)) atomicAdd(&hist[key], 1u);
+    // Two dependent loads per pixel (position, then the chain's output there): the positions of the
+    // NEXT eight rows are fetched a group ahead, the eight gathers of the current group go out
+    // together, so the loop pays one gather latency per 512 pixels instead of two per 64.
+    if (lo < hi) {
+        constexpr int kRows = 8;
+        uint32_t p_cur[kRows], p_nxt[kRows], r_cur[kRows], r_nxt[kRows], x_cur[kRows], x_nxt[kRows];
+        auto fetch = [&](uint32_t base, uint32_t (&pp)[kRows], uint32_t (&rr)[kRows], uint32_t (&xx)[kRows]) {
+#pragma unroll
+            for (int k = 0; k < kRows; k++) {
+                const uint32_t t = min(base + 64u * uint32_t(k) + uint32_t(lane_id()), hi - 1);
+                pp[k] = pos2[t]; rr[k] = rec1[t]; xx[k] = x[t];
+            }
+        };
+        fetch(lo, p_cur, r_cur, x_cur);
+        for (uint32_t gbase = lo; gbase < hi; gbase += 64u * kRows) {
+            fetch(gbase + 64u * kRows, p_nxt, r_nxt, x_nxt);
+            uint32_t v[kRows];
+#pragma unroll
+            for (int k = 0; k < kRows; k++) v[k] = s2out[p_cur[k]];
+#pragma unroll
+            for (int k = 0; k < kRows; k++) {
+                const uint32_t t = gbase + 64u * uint32_t(k) + uint32_t(lane_id());
+                if (t < hi) {
+                    const int vs = int(int16_t(v[k]));                 // context state >> 7 as the chain saw it
+                    const int sign = vs & 1;
+                    const uint16_t ps = uint16_t(iclip(s1_px0(r_cur[k]) + (vs >> 1) + sign, 0, kMaxVal) | (sign << 8));
+                    uint32_t key; int y;
+                    pxs[t] = ps;
+                    if (mapper_item(int(x_cur[k]), ps, key, y)) atomicAdd(&hist[key], 1u);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kRows; k++) { p_cur[k] = p_nxt[k]; r_cur[k] = r_nxt[k]; x_cur[k] = x_nxt[k]; }
         }
     }
     for (int k = lane_id(); k < 512; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
