@@ -106,16 +106,13 @@ NB_TARGET NB_INLINE void step_all(Regs &R, Outs &O, __m512i ev) {
     const __m512i hi = _mm512_add_epi64(R.lo, R.span);
     const __m512i x = _mm512_xor_si512(R.lo, hi);
     const __mmask8 k = _mm512_testn_epi64_mask(x, _mm512_set1_epi64(0xFF000000ll));         // top bytes agree: one byte out
+    const __mmask8 k2 = _mm512_testn_epi64_mask(x, _mm512_set1_epi64(0xFFFF0000ll));        // top two bytes agree (rare)
     R.acc = _mm512_mask_shldi_epi64(R.acc, k, R.acc, _mm512_slli_epi64(hi, 32), 8);          // acc = acc << 8 | hi >> 24
     R.cnt = _mm512_mask_add_epi64(R.cnt, k, R.cnt, _mm512_set1_epi64(1));
     R.lo = _mm512_mask_and_epi64(R.lo, k, _mm512_slli_epi64(R.lo, 8), _mm512_set1_epi64(0xFFFFFFFFll));
     R.span = _mm512_mask_or_epi64(R.span, k, _mm512_slli_epi64(R.span, 8), _mm512_set1_epi64(0xFF));
-    // the two unusual cases in ONE mask: an accumulator that is full (cnt == 8) or a second byte due
-    // (the top two bytes agree) -- min(cnt ^ 8, x & 0xFFFF0000) is zero exactly then
-    const __m512i odd = _mm512_min_epu64(_mm512_xor_si512(R.cnt, _mm512_set1_epi64(8)), _mm512_and_si512(x, _mm512_set1_epi64(0xFFFF0000ll)));
-    if (__builtin_expect(_mm512_testn_epi64_mask(odd, odd) != 0, 0)) {
-        const __mmask8 kf = _mm512_cmpeq_epi64_mask(R.cnt, _mm512_set1_epi64(8));
-        const __mmask8 k2 = _mm512_testn_epi64_mask(x, _mm512_set1_epi64(0xFFFF0000ll));
+    const __mmask8 kf = _mm512_cmpeq_epi64_mask(R.cnt, _mm512_set1_epi64(8));
+    if (__builtin_expect((kf | k2) != 0, 0)) {
         if (kf) flush_full(R, O, kf);
         __mmask8 kk = k2;
         while (kk) {                                          // further bytes of the same step, one at a time
