@@ -151,10 +151,10 @@ struct nblic_amd_ctx {
     int device = 0;
     long max_px = kMaxPixels;
     bool timing = false;
-    bool simd = false;                    // AVX-512 host: eight streams per coder step
+    bool simd = false;                    // AVX-512 host: up to sixteen images per coder thread (two packs in lock-step)
     std::vector<Group> groups;
     std::mutex api;                       // one batch at a time per context
-    std::mutex fm;                        // free groups / free host buffers / outstanding work
+    std::mutex fm;                        // free groups / free coded-bin buffers / outstanding work
     std::condition_variable fcv;
     std::deque<int> free_groups;
     bool trace = false;                      // NBLIC_AMD_DBG & 64: timeline of groups and coder takes on stderr
@@ -173,7 +173,7 @@ struct nblic_amd_ctx {
     int batch_to_come = 0;                // images of the running batch that have not reached `ready` yet (guarded by rm)
     bool stop = false;
     // One driver thread per group: a group's launch sequence has a host round trip in the middle
-    // (the event count sizes the back half) and may wait for a pinned buffer; with a thread each,
+    // (the event count sizes the back half) and may wait for a coded-bin buffer; with a thread each,
     // one group waiting never keeps the others from being launched.
     std::vector<std::thread> drivers;
     std::mutex dm;
@@ -184,7 +184,7 @@ struct nblic_amd_ctx {
     double stage_ms[kE1Kernels] = {0};
     long stage_launches = 0;
     double total_bins = 0, coder_s = 0;
-    double pack_bins = 0, pack_s = 0;     // the part of the above coded eight at a time
+    double pack_bins = 0, pack_s = 0;     // the part of the above coded in packs (2..16 images per thread)
     double wait_s = 0;                    // of coder_s: waiting for bins to arrive from HBM
     long takes[kMaxTake + 1] = {0};       // how many times a thread took k images together
     std::mutex stat_m;
