@@ -11,7 +11,10 @@ What the model does NOT capture, and the in-situ runs showed: the host share is 
 quota, so once every thread is busy the pipeline is paced by bins per CPU-second, not by per-thread
 speed.  Measured at 512 frames per step: greedy packs 3257 Mpixel/s; waiting mid-batch for full
 16-image packs 3382; an even-share drain from half-way through the batch 2976 (too many small,
-inefficient packs).  pipeline.hip ships the second."""
+inefficient packs).  pipeline.hip ships the second.  Also tried in situ: a two-slot scheduler
+per thread (packs of eight that start and finish independently at chunk boundaries and are stepped
+in lock-step whenever both are running) -- bit-exact, busy 88 % of the time, but 3250-3340
+Mpixel/s: the periods with one pack running alone cost what the continuous refill gains."""
 import heapq
 
 BINS = 74.5e6
