@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixel/s of bit-exact -n0 -e1 NBLIC encode on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of B synthetic 4096x4096 8-bit gray
+One "step" = one pass of the hot path over one batch of B (default 1024) synthetic 4096x4096 8-bit gray
 frames (SYN-1, BASELINE config 2) per GPU: the frames are already resident in HBM when the
 timed region starts; the step ends when every byte-exact .nblic stream is in host memory
 (and, for N > 1, gathered on rank 0 over RCCL).  Prints ONE JSON line on rank 0.
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (the pipeline's fill and drain, ~0.1 s + ~0.8 s, are inside every step)")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step (the pipeline's fill and drain, ~0.1 s + ~0.8 s, are inside every step)")
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--coders", type=int, default=0, help="host range-coder threads per GPU (0 = CPU share)")
@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--groups", type=int, default=6, help="launch groups the images in flight are split into")
     ap.add_argument("--host-buffers", type=int, default=0, help="coded-bin buffers in HBM between the GPU and the coder threads (0 = slots + 16*coders + 32)")
     ap.add_argument("--host-inputs", action="store_true", help="hand host buffers over (PCIe-inclusive rate)")
+    ap.add_argument("--gather-chunk", type=int, default=512, help="frames per exchange of the N>1 gather (bounds rank 0's receive buffers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 path be rehearsed with every rank on one GPU")
     args = ap.parse_args()
@@ -115,13 +116,16 @@ def main():
     coders = args.coders or max(1, min(B, 16, cpus // max(1, local_world)))   # 16 = one GPU's CPU share
     slots = args.slots or min(B, 48)
 
+    # frames are generated and uploaded 128 at a time: only the CPU baseline's sample (and, with
+    # --host-inputs, everything) stays on the host
     from concurrent.futures import ThreadPoolExecutor
+    frames, dev_frames = [], []
     with ThreadPoolExecutor(max_workers=max(1, min(16, cpus // max(1, local_world)))) as ex:   # the C generator releases the GIL
-        frames = list(ex.map(lambda k: pkg.syn1(H, W, seed=rank * B + k + 1), range(B)))
-    dev_frames = [torch.from_numpy(f).to(dev) for f in frames]
-    torch.cuda.synchronize()
-    if not args.host_inputs:
-        frames = frames[:8]                                   # the CPU baseline's sample; the rest lives in HBM only
+        for k0 in range(0, B, 128):
+            part = list(ex.map(lambda k: pkg.syn1(H, W, seed=rank * B + k + 1), range(k0, min(B, k0 + 128))))
+            dev_frames += [torch.from_numpy(f).to(dev) for f in part]
+            torch.cuda.synchronize()
+            frames += part if args.host_inputs else part[: max(0, 8 - len(frames))]
     host_buffers = args.host_buffers or min(B + 16, slots + 16 * coders + 32)   # groups in flight + every thread's sixteen + a queue
     ctx = pkg.Context(device=gpu, n_slots=slots, n_coders=coders, n_groups=max(1, min(args.groups, slots)),
                       n_host_buffers=host_buffers)
@@ -132,7 +136,8 @@ def main():
     slab = torch.empty((B, cap), dtype=torch.uint8, pin_memory=True)
     outs = [slab[k].numpy() for k in range(B)]
     shapes = [(H, W)] * B
-    dev_pack = torch.empty(B * cap, dtype=torch.uint8, device=comm_dev) if world > 1 else None
+    GATHER_CHUNK = max(1, args.gather_chunk)              # frames per exchange: bounds rank 0's receive buffers (world x 4.6 GB at 512)
+    dev_pack = torch.empty(min(B, GATHER_CHUNK) * cap, dtype=torch.uint8, device=comm_dev) if world > 1 else None
     ptrs = [f.ctypes.data for f in frames] if args.host_inputs else [d.data_ptr() for d in dev_frames]
     gather = None
     if world > 1:
@@ -144,12 +149,16 @@ def main():
         _, lens = ctx.encode_ptrs(ptrs, shapes, not args.host_inputs, outs)
         last["lens"] = lens
         if world > 1:                                   # the one exchange of the path: streams -> rank 0 (stay in HBM)
-            off = 0
-            for k in range(B):
-                n = int(lens[k])
-                dev_pack[off:off + n].copy_(slab[k, :n], non_blocking=True)
-                off += n
-            last["gathered"] = gather.gather_packed(dev_pack[:off], torch.from_numpy(lens).to(comm_dev))
+            for k0 in range(0, B, GATHER_CHUNK):
+                k1 = min(B, k0 + GATHER_CHUNK)
+                off = 0
+                for k in range(k0, k1):
+                    n = int(lens[k])
+                    dev_pack[off:off + n].copy_(slab[k, :n], non_blocking=True)
+                    off += n
+                last["gathered"] = None                 # release the previous receive buffers BEFORE the next ones are allocated
+                last["gathered"] = gather.gather_packed(dev_pack[:off], torch.from_numpy(lens[k0:k1]).to(comm_dev))
+                last["gathered_first"] = k0
 
     def fence():
         torch.cuda.synchronize()
@@ -183,10 +192,11 @@ def main():
 
     gathered_ok = None
     if world > 1 and rank == 0:
-        payloads, lens_all = last["gathered"]
+        payloads, lens_all = last["gathered"]             # the step's last exchange (frames gathered_first ..)
+        k0 = last["gathered_first"]
         gathered_ok = (len(payloads) == world and all(int(l.sum()) == p.numel() for p, l in zip(payloads, lens_all)) and
                        hashlib.sha256(payloads[0][: int(lens_all[0][0])].cpu().numpy().tobytes()).hexdigest() ==
-                       hashlib.sha256(outs[0][: int(lens[0])].tobytes()).hexdigest())
+                       hashlib.sha256(outs[k0][: int(lens[k0])].tobytes()).hexdigest())
     bit_exact = None
     if rank == 0:
         try:
