@@ -279,3 +279,23 @@ def test_sixteen_image_packs_and_chunked_streaming(pkg, oracle):
     for k, (img, g) in enumerate(zip(imgs, got)):
         assert g == oracle.encode(img, 0, 1)[0], (k, img.shape)
     assert again == got[:5]
+
+
+@pytest.mark.gpu
+def test_production_shaped_context_many_small_images(pkg, oracle):
+    """The bench's context shape (6 groups of 8, 16 coder threads, device-side backlog) fed 200
+    images of every content and size class, twice over: all groups, driver threads, copy streams and
+    coder threads are busy at once, packs form from images that end at wildly different bins."""
+    rng = np.random.default_rng(17)
+    imgs = []
+    for k in range(200):
+        h, w = int(rng.integers(1, 420)), int(rng.integers(1, 640))
+        imgs.append(inputs.make(inputs.CONTENTS[k % len(inputs.CONTENTS)], h, w) if k % 3 else inputs.syn1(h, w, seed=k + 1))
+    want = [oracle.encode(img, 0, 1)[0] for img in imgs]
+    ctx = pkg.Context(device=0, n_slots=48, n_coders=16, n_groups=6, n_host_buffers=336)
+    try:
+        for _ in range(2):
+            got = ctx.encode_batch(imgs)
+            assert got == want
+    finally:
+        ctx.close()
