@@ -85,6 +85,19 @@ int nblic_amd_encode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned char
                            const int *heights, const int *widths, unsigned char *const *outs,
                            const size_t *out_caps, long *out_lens);
 
+/* The same batch in two halves, so that several batches can be in flight: _begin hands the images
+ * to the GPU pipeline and returns as soon as the last of them has been handed over (it blocks only
+ * while every group is busy); _end waits until every stream of THAT batch has been written and
+ * returns 0 / -1 like nblic_amd_encode_batch.  While batch k drains through the host coder threads
+ * (~0.8 s for the last 16-image packs) batch k+1 is already filling the GPU: a continuous feed
+ * never sees the pipeline's fill and drain.  All argument arrays and buffers of a batch must stay
+ * valid, and its outputs untouched, until its _end; batches may be ended in any order.        */
+typedef struct nblic_amd_batch nblic_amd_batch;
+nblic_amd_batch *nblic_amd_encode_batch_begin(nblic_amd_ctx *ctx, int n_images, const unsigned char *const *imgs,
+                                              int imgs_on_device, const int *heights, const int *widths,
+                                              unsigned char *const *outs, const size_t *out_caps, long *out_lens);
+int nblic_amd_encode_batch_end(nblic_amd_ctx *ctx, nblic_amd_batch *batch);
+
 /* Same for effort 0 (QNBLIC): the per-pixel model runs on the GPU, the entropy stage (histogram
  * normalisation, histogram code, rANS) on a coder thread.  outs[k] are uint16_t buffers; capacities
  * and lengths are in 16-bit WORDS, like QNBLICcompress's return value.                         */

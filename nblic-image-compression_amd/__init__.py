@@ -35,7 +35,7 @@ _lib = None
 # every symbol include/nblic_amd.h declares
 EXPORTS = (
     "NBLICcompress", "NBLICdecompress", "QNBLICcompress", "QNBLICdecompress", "QNBLICcompressMultiThread",
-    "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_qencode_batch", "nblic_amd_set_max_pixels",
+    "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_encode_batch_begin", "nblic_amd_encode_batch_end", "nblic_amd_qencode_batch", "nblic_amd_set_max_pixels",
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
     "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_range_code_chunked", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
 )
@@ -82,6 +82,11 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_encode_batch.restype = C.c_int
     lib.nblic_amd_encode_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, ip, ip,
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
+    lib.nblic_amd_encode_batch_begin.restype = C.c_void_p
+    lib.nblic_amd_encode_batch_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, ip, ip,
+                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
+    lib.nblic_amd_encode_batch_end.restype = C.c_int
+    lib.nblic_amd_encode_batch_end.argtypes = [C.c_void_p, C.c_void_p]
     lib.nblic_amd_qencode_batch.restype = C.c_int
     lib.nblic_amd_qencode_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, ip, ip,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
@@ -288,6 +293,32 @@ class Context:
         if rc != 0:
             raise RuntimeError(f"nblic_amd_encode_batch failed (lengths {arr.tolist()})")
         return outs, arr
+
+    def encode_begin(self, ptrs: Sequence[int], shapes: Sequence[Tuple[int, int]], on_device: bool,
+                     outs: Optional[List[np.ndarray]] = None):
+        """Submit a batch (``nblic_amd_encode_batch_begin``); returns a ticket for :meth:`encode_end`.
+        Several batches may be in flight; the ticket keeps every argument array alive."""
+        k = len(ptrs)
+        if outs is None:
+            outs = [np.empty(out_capacity(h, w), np.uint8) for (h, w) in shapes]
+        imgs = (C.c_void_p * k)(*[C.c_void_p(int(p)) for p in ptrs])
+        hs = (C.c_int * k)(*[int(s[0]) for s in shapes])
+        ws = (C.c_int * k)(*[int(s[1]) for s in shapes])
+        op = (C.c_void_p * k)(*[C.c_void_p(o.ctypes.data) for o in outs])
+        caps = (C.c_size_t * k)(*[o.size for o in outs])
+        lens = (C.c_long * k)()
+        handle = self.lib.nblic_amd_encode_batch_begin(self.handle, k, imgs, int(on_device), hs, ws, op, caps, lens)
+        if not handle:
+            raise RuntimeError("nblic_amd_encode_batch_begin failed")
+        return {"handle": handle, "keep": (imgs, hs, ws, op, caps), "lens": lens, "outs": outs, "n": k}
+
+    def encode_end(self, ticket) -> Tuple[List[np.ndarray], np.ndarray]:
+        """Wait for a batch submitted with :meth:`encode_begin`.  Returns (out buffers, lengths)."""
+        rc = self.lib.nblic_amd_encode_batch_end(self.handle, ticket["handle"])
+        lens = np.array(ticket["lens"][:], np.int64)
+        if rc != 0:
+            raise RuntimeError(f"nblic_amd_encode_batch_end failed (lengths {list(lens[:8])}...)")
+        return ticket["outs"], lens
 
     def encode_batch(self, imgs: Sequence[np.ndarray]) -> List[bytes]:
         """-n0 -e1 encode of host planes; returns the .nblic streams."""

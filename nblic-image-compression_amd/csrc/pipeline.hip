@@ -100,11 +100,17 @@ constexpr size_t kChunkBins = size_t(1) << 20;                     // bins per l
 constexpr int kCopyStreams = 4;
 constexpr int kMaxTake = 16;                                       // images one coder thread codes together (two AVX-512 packs)
 
+}  // namespace nblic
+// One submitted batch (nblic_amd_encode_batch_begin .. _end); `remaining` is guarded by ctx->fm.
+struct nblic_amd_batch { int remaining = 0; int n_images = 0; long *lens = nullptr; bool ok = true; };
+namespace nblic {
+
 struct ReadyImage {                                                  // everything a coder thread needs
     int cb, job, h, w;
     uint32_t n_ev;
     unsigned char *const *outs; const size_t *caps; long *lens;      // -e1: byte streams; effort 0: uint16_t streams, caps/lens in words
     int kind;                                                        // 0 = NBLIC -e1 range coder, 1 = QNBLIC entropy stage
+    ::nblic_amd_batch *batch;                                        // whose completion this image counts towards
 };
 
 // ---- one image in flight -------------------------------------------------------------------
@@ -132,6 +138,7 @@ struct Group {
     // the batch this group currently serves (valid from launch_back until its coders finish)
     unsigned char *const *outs = nullptr; const size_t *caps = nullptr; long *lens = nullptr;
     int kind = 0;
+    ::nblic_amd_batch *batch = nullptr;
     // hand-over to the group's driver thread (guarded by ctx->dm)
     const uint8_t *const *imgs = nullptr; bool on_device = false; bool has_work = false;
 };
@@ -406,7 +413,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
                 c->failed = true;
             }
             q.lens[q.job] = words_out;
-            { std::lock_guard<std::mutex> l(c->fm); c->free_cbufs.push_back(q.cb); c->coding -= 1; }
+            { std::lock_guard<std::mutex> l(c->fm); c->free_cbufs.push_back(q.cb); c->coding -= 1; if (q.batch) q.batch->remaining -= 1; }
             c->fcv.notify_all();
             continue;
         }
@@ -437,7 +444,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
         { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; if (take > 1) { c->pack_bins += bins; c->pack_s += dt; } c->wait_s += t.wait_s; t.wait_s = 0; c->takes[take]++; }
         {
             std::lock_guard<std::mutex> l(c->fm);
-            for (int k = 0; k < take; k++) c->free_cbufs.push_back(im[k].cb);
+            for (int k = 0; k < take; k++) { c->free_cbufs.push_back(im[k].cb); if (im[k].batch) im[k].batch->remaining -= 1; }
             c->coding -= take;
         }
         c->fcv.notify_all();
@@ -474,7 +481,7 @@ static void on_group_done(void *vp) {
         std::lock_guard<std::mutex> l(c->rm);
         for (int k = 0; k < gp->n_jobs; k++) {
             const Slot &s = gp->slots[size_t(k)];
-            c->ready.push_back(ReadyImage{s.cb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens, gp->kind});
+            c->ready.push_back(ReadyImage{s.cb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens, gp->kind, gp->batch});
         }
         c->batch_to_come -= gp->n_jobs;
     }
@@ -547,7 +554,7 @@ static void driver_main(nblic_amd_ctx *c, int id) {
             }
             { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come -= g.n_jobs; }
             c->rcv.notify_all();                                 // a pack may be waiting for images that will not come
-            { std::lock_guard<std::mutex> l(c->fm); c->coding -= g.n_jobs; }
+            { std::lock_guard<std::mutex> l(c->fm); c->coding -= g.n_jobs; if (g.batch) { g.batch->remaining -= g.n_jobs; g.batch->ok = false; } }
             release_group(c, id);
         }
     }
@@ -556,25 +563,32 @@ static void driver_main(nblic_amd_ctx *c, int id) {
 // The images are counted as outstanding BEFORE the driver thread is woken, so the batch's final
 // wait cannot slip through between the hand-over and the launch.
 static void start_group(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, bool on_device) {
-    { std::lock_guard<std::mutex> l(c->fm); c->coding += g.n_jobs; }
+    { std::lock_guard<std::mutex> l(c->fm); c->coding += g.n_jobs; if (g.batch) g.batch->remaining += g.n_jobs; }
     { std::lock_guard<std::mutex> l(c->dm); g.imgs = imgs; g.on_device = on_device; g.has_work = true; }
     c->dcv.notify_all();
 }
 
 // Groups are started one after the other and run concurrently on the GPU (a stream each); the
 // host codes finished groups while the GPU is busy with the following ones.
-static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *imgs, bool on_device, const int *hs,
-                         const int *ws, uint8_t *const *outs, const size_t *caps, long *lens) {
-    if (hipSetDevice(c->device) != hipSuccess) return false;
-    for (auto &v : c->stage_ms) v = 0;
-    c->stage_launches = 0;
-    c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; for (auto &v : c->takes) v = 0;
-    bool ok = true;
-    c->failed = false;
-    c->t_batch = std::chrono::steady_clock::now();
-    c->trace = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 64);
+// Submission half of a batch: hands the images to the groups (blocks only while all groups are
+// busy, i.e. until the GPU is down to its last few groups of this batch).  The coder threads and the
+// groups still in flight finish on their own; encode_wait() collects.  Several batches may be
+// outstanding: the next one fills the pipeline while this one drains.
+static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, const uint8_t *const *imgs, bool on_device,
+                          const int *hs, const int *ws, uint8_t *const *outs, const size_t *caps, long *lens) {
+    bool idle;
+    { std::lock_guard<std::mutex> l(c->fm); idle = c->coding == 0; }
+    if (idle) {                                                   // nothing outstanding: start the reporting afresh
+        for (auto &v : c->stage_ms) v = 0;
+        c->stage_launches = 0;
+        c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; for (auto &v : c->takes) v = 0;
+        c->failed = false;
+        c->t_batch = std::chrono::steady_clock::now();
+        c->trace = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 64);
+    }
+    b->n_images = n_images; b->lens = lens;
     for (int k = 0; k < n_images; k++) lens[k] = -1;
-    { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come = n_images; }
+    { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come += n_images; }
     int next = 0;
     while (next < n_images) {
         int id;
@@ -585,28 +599,43 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
         }
         Group &g = c->groups[size_t(id)];
         collect_timing(c, g);                               // events of its previous use are complete by now
-        g.outs = outs; g.caps = caps; g.lens = lens; g.kind = 0;
+        g.outs = outs; g.caps = caps; g.lens = lens; g.kind = 0; g.batch = b;
         g.n_jobs = 0;
         while (next < n_images && g.n_jobs < int(g.slots.size())) {
             int k = next++;
-            if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; std::lock_guard<std::mutex> l(c->rm); c->batch_to_come--; continue; }
+            if (!size_ok(hs[k], ws[k], c->max_px)) { b->ok = false; std::lock_guard<std::mutex> l(c->rm); c->batch_to_come--; continue; }
             Slot &s = g.slots[size_t(g.n_jobs++)];
             s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1;
         }
         if (g.n_jobs == 0) { release_group(c, id); continue; }
         start_group(c, g, imgs, on_device);
     }
-    {   // wait for the coder threads (and with them every group's GPU work)
+}
+
+static bool encode_wait(nblic_amd_ctx *c, nblic_amd_batch *b) {
+    {   // wait for the coder threads (and with them every group's GPU work) of THIS batch
         std::unique_lock<std::mutex> l(c->fm);
-        c->fcv.wait(l, [c] { return c->coding == 0; });
+        c->fcv.wait(l, [b] { return b->remaining == 0; });
     }
-    for (auto &g : c->groups) collect_timing(c, g);
+    bool ok = b->ok;
+    for (int k = 0; k < b->n_images; k++) if (b->lens[k] < 0) ok = false;
+    return ok;
+}
+
+static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *imgs, bool on_device, const int *hs,
+                         const int *ws, uint8_t *const *outs, const size_t *caps, long *lens) {
+    if (hipSetDevice(c->device) != hipSuccess) return false;
+    nblic_amd_batch b;
+    { std::lock_guard<std::mutex> g(c->api); encode_submit(c, &b, n_images, imgs, on_device, hs, ws, outs, caps, lens); }
+    bool ok = encode_wait(c, &b);
+    bool idle;
+    { std::lock_guard<std::mutex> l(c->fm); idle = c->coding == 0; }
+    if (idle) for (auto &g : c->groups) collect_timing(c, g);
     if (getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 32))
         fprintf(stderr, "[nblic_amd] coder: singles %.0f Mbins in %.2f thread-s (%.0f Mbins/s), packs %.0f Mbins in %.2f thread-s (%.0f Mbins/s)\n",
                 (c->total_bins - c->pack_bins) / 1e6, c->coder_s - c->pack_s, (c->total_bins - c->pack_bins) / 1e6 / (c->coder_s - c->pack_s + 1e-9),
                 c->pack_bins / 1e6, c->pack_s, c->pack_bins / 1e6 / (c->pack_s + 1e-9)),
         fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that waiting for chunks; takes of 1/2-7/8/9-15/16 images: %ld/%ld/%ld/%ld/%ld\n", c->wait_s, c->takes[1], c->takes[2] + c->takes[3] + c->takes[4] + c->takes[5] + c->takes[6] + c->takes[7], c->takes[8], c->takes[9] + c->takes[10] + c->takes[11] + c->takes[12] + c->takes[13] + c->takes[14] + c->takes[15], c->takes[16]);
-    for (int k = 0; k < n_images; k++) if (lens[k] < 0) ok = false;
     return ok && !c->failed;
 }
 
@@ -648,7 +677,7 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
     bool ok = true;
     c->failed = false;
     for (int k = 0; k < n_images; k++) len_words[k] = -1;
-    { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come = n_images; }
+    { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come += n_images; }
     int next = 0;
     while (next < n_images) {
         int id;
@@ -659,7 +688,7 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
         }
         Group &g = c->groups[size_t(id)];
         collect_timing(c, g);
-        g.outs = reinterpret_cast<unsigned char *const *>(outs); g.caps = caps_words; g.lens = len_words; g.kind = 1;
+        g.outs = reinterpret_cast<unsigned char *const *>(outs); g.caps = caps_words; g.lens = len_words; g.kind = 1; g.batch = nullptr;
         g.n_jobs = 0;
         while (next < n_images && g.n_jobs < int(g.slots.size())) {
             int k = next++;
@@ -838,8 +867,24 @@ int nblic_amd_encode_batch(nblic_amd_ctx *c, int n_images, const unsigned char *
                            const int *heights, const int *widths, unsigned char *const *outs, const size_t *out_caps,
                            long *out_lens) {
     if (!c || n_images < 0) return -1;
-    std::lock_guard<std::mutex> g(c->api);
     return encode_batch(c, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps, out_lens) ? 0 : -1;
+}
+
+nblic_amd_batch *nblic_amd_encode_batch_begin(nblic_amd_ctx *c, int n_images, const unsigned char *const *imgs, int imgs_on_device,
+                                              const int *heights, const int *widths, unsigned char *const *outs,
+                                              const size_t *out_caps, long *out_lens) {
+    if (!c || n_images < 0 || hipSetDevice(c->device) != hipSuccess) return nullptr;
+    auto *b = new nblic_amd_batch;
+    std::lock_guard<std::mutex> g(c->api);
+    encode_submit(c, b, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps, out_lens);
+    return b;
+}
+
+int nblic_amd_encode_batch_end(nblic_amd_ctx *c, nblic_amd_batch *b) {
+    if (!c || !b) return -1;
+    const bool ok = encode_wait(c, b) && !c->failed;
+    delete b;
+    return ok ? 0 : -1;
 }
 
 long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, int w, int which, void *out, size_t out_bytes) {

@@ -299,3 +299,30 @@ def test_production_shaped_context_many_small_images(pkg, oracle):
             assert got == want
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_overlapping_batches_begin_end(pkg, oracle):
+    """Three batches in flight at once (nblic_amd_encode_batch_begin / _end), ended out of order:
+    every batch gets exactly its own streams."""
+    rng = np.random.default_rng(23)
+    batches = []
+    for b in range(3):
+        imgs = []
+        for k in range(30):
+            h, w = int(rng.integers(40, 500)), int(rng.integers(40, 600))
+            imgs.append(inputs.make(inputs.CONTENTS[(k + b) % len(inputs.CONTENTS)], h, w) if k % 2 else inputs.syn1(h, w, seed=100 * b + k + 1))
+        batches.append(imgs)
+    ctx = pkg.Context(device=0, n_slots=12, n_coders=4, n_groups=3, n_host_buffers=64)
+    try:
+        tickets = [ctx.encode_begin([i.ctypes.data for i in imgs], [i.shape for i in imgs], False) for imgs in batches]
+        results = {}
+        for b in (1, 0, 2):
+            outs, lens = ctx.encode_end(tickets[b])
+            results[b] = [o[:int(n)].tobytes() for o, n in zip(outs, lens)]
+        again = ctx.encode_batch(batches[0][:3])                 # the synchronous call still works afterwards
+    finally:
+        ctx.close()
+    for b, imgs in enumerate(batches):
+        assert results[b] == [oracle.encode(img, 0, 1)[0] for img in imgs], b
+    assert again == results[0][:3]
