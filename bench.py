@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 # The pipeline keeps 6 group streams + 4 copy streams + 1 serial-engine stream busy.  The HIP runtime
 # multiplexes streams onto 4 hardware queues by default, which puts the coder threads' copies
 # behind other groups' kernels; it reads this when it initialises, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy
 

@@ -22,7 +22,7 @@ import numpy as np
 
 # The batch pipeline keeps 6 group streams + 4 copy streams busy; the HIP runtime multiplexes
 # streams onto 4 hardware queues by default and reads this when it initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnblic_amd.so")

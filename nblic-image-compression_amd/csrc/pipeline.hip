@@ -8,6 +8,7 @@
 // already working on the next images.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -19,6 +20,8 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "../../include/nblic_amd.h"
 #include "kernels_e1.h"
@@ -95,9 +98,30 @@ bool size_ok(int h, int w, long max_px) {                                       
 // The backlog lives in HBM: a finished image's coded bins stay in a device buffer until a coder
 // thread streams them to the host chunk by chunk (its own small pinned ring), so the pinned host
 // memory is per THREAD, not per image, and the GPU never waits for host buffers.
+// Host memory the coder threads READ at full speed: ordinary pages, first touched by the thread
+// that will read them (so they sit on its NUMA node), then page-locked in place.  hipHostMalloc'ed
+// memory reads 14-18 % slower from these threads (measured: 1650 vs 1950 Mbins/s through the
+// sixteen-lane coder, tools/pinned_coder_bench.py).
+static uint16_t *locked_alloc(size_t words) {
+    if (getenv("NBLIC_AMD_HOSTMALLOC")) { void *q = nullptr; return hipHostMalloc(&q, words * sizeof(uint16_t), hipHostMallocDefault) == hipSuccess ? static_cast<uint16_t *>(q) : nullptr; }
+    const size_t bytes = (words * sizeof(uint16_t) + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+    void *p = aligned_alloc(size_t(2) << 20, bytes);
+    if (!p) return nullptr;
+    madvise(p, bytes, MADV_HUGEPAGE);
+    memset(p, 0, bytes);
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { free(p); return nullptr; }
+    return static_cast<uint16_t *>(p);
+}
+static void locked_free(uint16_t *p) {
+    if (!p) return;
+    if (getenv("NBLIC_AMD_HOSTMALLOC")) { hipHostFree(p); return; }
+    hipHostUnregister(p);
+    free(p);
+}
+
 struct CodedBuf { uint16_t *p = nullptr; size_t cap = 0; };        // device; one image's coded bins (QNBLIC: pairs + histograms)
 constexpr size_t kChunkBins = size_t(1) << 20;                     // bins per lane per chunk of the host ring
-constexpr int kCopyStreams = 4;
+constexpr int kCopyStreams = 8;
 constexpr int kMaxTake = 16;                                       // images one coder thread codes together (two AVX-512 packs)
 
 }  // namespace nblic
@@ -288,6 +312,26 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
     return true;
 }
 
+// ---- bins leave HBM in the layout the host coder wants ---------------------------------------
+// rows[16 * i + lane] = bins 4i .. 4i+3 of lane `lane` as one 64-bit word (zero past the lane's end):
+// a chunk of up to sixteen images becomes ONE contiguous device->host copy (instead of sixteen), and
+// on the host a pack's next four steps are one aligned 64-byte load (instead of an 8-way gather).
+// (Measured and rejected: letting this kernel store straight into the mapped host ring.  The
+// PCIe-bound waves crowd the encoder's own kernels off the GPU: 4.6 -> 2.4 Gpx/s.)
+struct InterleaveArgs { const uint16_t *src[kMaxTake]; uint32_t len[kMaxTake]; };
+__global__ void __launch_bounds__(256) k_interleave16(InterleaveArgs a, uint64_t *__restrict__ rows, uint32_t n_rows) {
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; (t >> 4) < n_rows; t += gridDim.x * 256u) {
+        const uint32_t lane = t & 15u, pos = 4u * (t >> 4), len = a.len[lane];
+        uint64_t v = 0;
+        if (pos + 4u <= len) {
+            v = *reinterpret_cast<const uint64_t *>(a.src[lane] + pos);  // chunk starts are multiples of 4 bins in 256-byte aligned buffers
+        } else {
+            for (uint32_t k = 0; k < 4u; k++) if (pos + k < len) v |= uint64_t(a.src[lane][pos + k]) << (16u * k);
+        }
+        rows[t] = v;
+    }
+}
+
 // What a coder thread owns: a pinned ring of two half-buffers x sixteen lanes x kChunkBins, so chunk
 // c+1 lands while chunk c is coded.  Its device->host copies go through one of the context's few
 // copy streams: a stream per thread would outnumber the hardware queues, and streams that share a
@@ -296,6 +340,7 @@ struct CoderThread {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     uint16_t *ring = nullptr;
+    uint64_t *d_rows = nullptr;                          // device: two halves of interleaved rows (k_interleave16's output)
     uint16_t *whole = nullptr; size_t whole_cap = 0;     // pinned; one whole QNBLIC image (its rANS runs last pixel first)
     RangeX8 x8, x8b;
     RangeScalar x1;
@@ -307,11 +352,13 @@ struct CoderThread {
         return true;
     }
     void destroy() {
-        if (ring) hipHostFree(ring);
-        if (whole) hipHostFree(whole);
+        locked_free(ring);
+        locked_free(whole);
+        if (d_rows) hipFree(d_rows);
         for (auto &e : ev) if (e) hipEventDestroy(e);
     }
     uint16_t *slot(int half, int lane) { return ring + (size_t(half) * kMaxTake + size_t(lane)) * kChunkBins; }
+    uint64_t *rows(int half) { return reinterpret_cast<uint64_t *>(ring) + size_t(half) * (kChunkBins / 4 * kMaxTake); }   // same bytes as the lanes' slots
 };
 
 // Streams `take` images' bins from HBM and codes them: one image with the scalar coder, up to
@@ -319,21 +366,39 @@ struct CoderThread {
 // lens[k] = coder bytes or SIZE_MAX.
 static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size_t *n, int take, uint8_t *const *dst,
                           const size_t *caps, size_t *lens) {
-    if (!t.ring) HIP_OK(hipHostMalloc((void **)&t.ring, 2 * kMaxTake * kChunkBins * sizeof(uint16_t), hipHostMallocDefault));
+    if (!t.ring && !(t.ring = locked_alloc(2 * kMaxTake * kChunkBins))) { fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
+    if (take > 1 && !t.d_rows) HIP_OK(hipMalloc((void **)&t.d_rows, 2 * (kChunkBins / 4 * kMaxTake) * sizeof(uint64_t)));
     size_t n_max = 0;
     for (int k = 0; k < take; k++) n_max = n[k] > n_max ? n[k] : n_max;
     const size_t chunks = (n_max + kChunkBins - 1) / kChunkBins;
     auto chunk_len = [&](size_t c, int k) { const size_t off = c * kChunkBins; return off >= n[k] ? size_t(0) : (n[k] - off < kChunkBins ? n[k] - off : kChunkBins); };
+    // two packs in lock-step whenever there is more than one image: a lone pack is bound by the
+    // latency of its own dependent chain, a second one rides along almost for free.  Pack a takes
+    // the first half of the images (lanes 0..), pack b the rest (lanes 8..).
+    const int na = take > 1 ? (take + 1) / 2 : 0, nb = take > 1 ? take - na : 0;
+    auto lane_of = [&](int k) { return k < na ? k : 8 + (k - na); };
     auto issue = [&](size_t c) -> bool {
-        for (int k = 0; k < take; k++)
-            if (size_t len = chunk_len(c, k))
-                HIP_OK(hipMemcpyAsync(t.slot(int(c & 1), k), dev[k] + c * kChunkBins, len * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
+        if (take == 1) {                                      // one image: its bins as they are, for the scalar coder
+            HIP_OK(hipMemcpyAsync(t.slot(int(c & 1), 0), dev[0] + c * kChunkBins, chunk_len(c, 0) * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
+        } else {                                              // a pack pair: interleaved on the GPU, one copy
+            InterleaveArgs a{};
+            size_t longest = 0;
+            for (int k = 0; k < take; k++) {
+                const size_t len = chunk_len(c, k);
+                a.src[lane_of(k)] = dev[k] + c * kChunkBins; a.len[lane_of(k)] = uint32_t(len);
+                longest = len > longest ? len : longest;
+            }
+            const uint32_t n_rows = uint32_t((longest + 3) / 4);
+            uint64_t *d = t.d_rows + size_t(c & 1) * (kChunkBins / 4 * kMaxTake);
+            if (n_rows) {
+                hipLaunchKernelGGL(k_interleave16, dim3((n_rows * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_rows);
+                HIP_OK(hipGetLastError());
+                HIP_OK(hipMemcpyAsync(t.rows(int(c & 1)), d, size_t(n_rows) * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
+            }
+        }
         HIP_OK(hipEventRecord(t.ev[c & 1], t.stream));
         return true;
     };
-    // two packs in lock-step whenever there is more than one image: a lone pack is bound by the
-    // latency of its own dependent chain, a second one rides along almost for free
-    const int na = take > 1 ? (take + 1) / 2 : 0, nb = take > 1 ? take - na : 0;
     if (take > 1) { t.x8.begin(na, dst, caps); t.x8b.begin(nb, dst + na, caps + na); }
     else t.x1.begin(dst[0], caps[0]);
     if (chunks && !issue(0)) return false;
@@ -342,10 +407,13 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
         auto w0 = std::chrono::steady_clock::now();
         HIP_OK(hipEventSynchronize(t.ev[c & 1]));
         t.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-        const uint16_t *src[kMaxTake + 8]; size_t len[kMaxTake + 8];
-        for (int k = 0; k < kMaxTake + 8; k++) { src[k] = k < kMaxTake ? t.slot(int(c & 1), k) : nullptr; len[k] = k < take ? chunk_len(c, k) : 0; }
-        if (take > 1) feed_pair(t.x8, src, len, t.x8b, src + na, len + na);
-        else t.x1.feed(src[0], len[0]);
+        if (take > 1) {
+            size_t len[kMaxTake] = {0};
+            for (int k = 0; k < take; k++) len[lane_of(k)] = chunk_len(c, k);
+            feed_pair_rows(t.x8, t.x8b, t.rows(int(c & 1)), len);
+        } else {
+            t.x1.feed(t.slot(int(c & 1), 0), chunk_len(c, 0));
+        }
     }
     if (take > 1) { t.x8.end(lens); t.x8b.end(lens + na); }
     else lens[0] = t.x1.finish();
@@ -397,9 +465,9 @@ static void coder_main(nblic_amd_ctx *c, int index) {
             const size_t n = size_t(q.h) * size_t(q.w), n_pad = (n + 1) & ~size_t(1), words = n_pad + 2 * 12 * 256;
             bool ok = true;
             if (t.whole_cap < words) {
-                if (t.whole) hipHostFree(t.whole);
+                locked_free(t.whole);
                 t.whole = nullptr; t.whole_cap = 0;
-                if (hipHostMalloc((void **)&t.whole, (words + 1024) * sizeof(uint16_t), hipHostMallocDefault) == hipSuccess) t.whole_cap = words + 1024;
+                if ((t.whole = locked_alloc(words + 1024)) != nullptr) t.whole_cap = words + 1024;
                 else ok = false;
             }
             ok = ok && hipMemcpyAsync(t.whole, c->cbufs[size_t(q.cb)].p, words * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream) == hipSuccess &&
@@ -612,6 +680,18 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
     }
 }
 
+static void report_coders(nblic_amd_ctx *c) {                        // NBLIC_AMD_DBG & 32, when nothing is outstanding
+    bool idle;
+    { std::lock_guard<std::mutex> l(c->fm); idle = c->coding == 0; }
+    if (!idle || !(getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 32))) return;
+    fprintf(stderr, "[nblic_amd] coder: singles %.0f Mbins in %.2f thread-s (%.0f Mbins/s), packs %.0f Mbins in %.2f thread-s (%.0f Mbins/s)\n",
+            (c->total_bins - c->pack_bins) / 1e6, c->coder_s - c->pack_s, (c->total_bins - c->pack_bins) / 1e6 / (c->coder_s - c->pack_s + 1e-9),
+            c->pack_bins / 1e6, c->pack_s, c->pack_bins / 1e6 / (c->pack_s + 1e-9));
+    fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that waiting for chunks; takes of 1/2-7/8/9-15/16 images: %ld/%ld/%ld/%ld/%ld\n", c->wait_s, c->takes[1],
+            c->takes[2] + c->takes[3] + c->takes[4] + c->takes[5] + c->takes[6] + c->takes[7], c->takes[8],
+            c->takes[9] + c->takes[10] + c->takes[11] + c->takes[12] + c->takes[13] + c->takes[14] + c->takes[15], c->takes[16]);
+}
+
 static bool encode_wait(nblic_amd_ctx *c, nblic_amd_batch *b) {
     {   // wait for the coder threads (and with them every group's GPU work) of THIS batch
         std::unique_lock<std::mutex> l(c->fm);
@@ -631,11 +711,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
     bool idle;
     { std::lock_guard<std::mutex> l(c->fm); idle = c->coding == 0; }
     if (idle) for (auto &g : c->groups) collect_timing(c, g);
-    if (getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 32))
-        fprintf(stderr, "[nblic_amd] coder: singles %.0f Mbins in %.2f thread-s (%.0f Mbins/s), packs %.0f Mbins in %.2f thread-s (%.0f Mbins/s)\n",
-                (c->total_bins - c->pack_bins) / 1e6, c->coder_s - c->pack_s, (c->total_bins - c->pack_bins) / 1e6 / (c->coder_s - c->pack_s + 1e-9),
-                c->pack_bins / 1e6, c->pack_s, c->pack_bins / 1e6 / (c->pack_s + 1e-9)),
-        fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that waiting for chunks; takes of 1/2-7/8/9-15/16 images: %ld/%ld/%ld/%ld/%ld\n", c->wait_s, c->takes[1], c->takes[2] + c->takes[3] + c->takes[4] + c->takes[5] + c->takes[6] + c->takes[7], c->takes[8], c->takes[9] + c->takes[10] + c->takes[11] + c->takes[12] + c->takes[13] + c->takes[14] + c->takes[15], c->takes[16]);
+    report_coders(c);
     return ok && !c->failed;
 }
 
@@ -757,15 +833,27 @@ int nblic_amd_range_code_chunked(const uint16_t *const *coded, const size_t *n, 
         }
         return 0;
     }
+    // as in the coder threads: pack a takes the first half of the streams (lanes 0..), pack b the rest
+    // (lanes 8..), each chunk is laid out in rows of sixteen 64-bit words (here on the host, in the
+    // pipeline by k_interleave16 on the GPU) and fed through feed_pair_rows
     RangeX8 a, b;
     const int na = (count + 1) / 2;
     a.begin(na, outs, caps);
     b.begin(count - na, outs + na, caps + na);
+    const size_t rows_cap = (chunk + 3) / 4 * 16;
+    uint64_t *rows = static_cast<uint64_t *>(aligned_alloc(64, (rows_cap * sizeof(uint64_t) + 63) & ~size_t(63)));
+    if (!rows) return -1;
     for (size_t off = 0; off < n_max; off += chunk) {
-        const uint16_t *src[kMaxTake + 8] = {nullptr}; size_t len[kMaxTake + 8] = {0};
-        for (int k = 0; k < count; k++) { src[k] = coded[k] + off; len[k] = off >= n[k] ? 0 : (n[k] - off < chunk ? n[k] - off : chunk); }
-        feed_pair(a, src, len, b, src + na, len + na);
+        size_t len[16] = {0};
+        memset(rows, 0, rows_cap * sizeof(uint64_t));
+        for (int k = 0; k < count; k++) {
+            const int lane = k < na ? k : 8 + (k - na);
+            len[lane] = off >= n[k] ? 0 : (n[k] - off < chunk ? n[k] - off : chunk);
+            for (size_t i = 0; i < len[lane]; i++) rows[16 * (i >> 2) + size_t(lane)] |= uint64_t(coded[k][off + i]) << (16 * (i & 3));
+        }
+        feed_pair_rows(a, b, rows, len);
     }
+    free(rows);
     a.end(lens);
     b.end(lens + na);
     return 0;
@@ -883,6 +971,7 @@ nblic_amd_batch *nblic_amd_encode_batch_begin(nblic_amd_ctx *c, int n_images, co
 int nblic_amd_encode_batch_end(nblic_amd_ctx *c, nblic_amd_batch *b) {
     if (!c || !b) return -1;
     const bool ok = encode_wait(c, b) && !c->failed;
+    report_coders(c);
     delete b;
     return ok ? 0 : -1;
 }

@@ -36,6 +36,10 @@ struct RangeX8 {
 // two packs (sixteen streams) advanced in lock-step by one thread
 void feed_pair(RangeX8 &a, const uint16_t *const *src_a, const size_t *len_a, RangeX8 &b, const uint16_t *const *src_b, const size_t *len_b);
 
+// the same from row-interleaved bins: rows[16 * i + lane] = bins 4i..4i+3 of lane `lane` as one 64-bit word
+// (64-byte aligned; lanes 0-7 pack a, 8-15 pack b); len[lane] = the lane's bins in this chunk
+void feed_pair_rows(RangeX8 &a, RangeX8 &b, const uint64_t *rows, const size_t *len);
+
 bool have_avx512();
 size_t range_code(const uint16_t *coded, size_t n, uint8_t *out, size_t cap);
 void range_code_x8(const uint16_t *const *coded, const size_t *n, int count, uint8_t *const *outs, const size_t *caps, size_t *lens);

@@ -241,6 +241,49 @@ NB_TARGET void feed_pair(RangeX8 &A, const uint16_t *const *src_a, const size_t 
     B.feed(rb, lb);
 }
 
+// The same pair fed from ROW-INTERLEAVED bins: rows[16 * i + lane] holds, as one 64-bit word, bins
+// 4i .. 4i+3 of lane `lane` (lanes 0-7 = pack A, 8-15 = pack B; zero where a lane has no bin).  That is
+// exactly what the gathers above assemble, so with this layout -- which a GPU kernel produces for the
+// coder threads before the bins leave HBM (k_interleave16) -- a pack's next four steps are ONE
+// aligned 64-byte load, and a chunk of sixteen images is one contiguous copy.  len[lane] = bins of
+// the lane in this chunk (0 = idle).
+NB_TARGET void feed_pair_rows(RangeX8 &A, RangeX8 &B, const uint64_t *rows, const size_t *len) {
+    Regs RA = A.st->L.r, RB = B.st->L.r;
+    Outs &OA = A.st->L.o, &OB = B.st->L.o;
+    const int ca = A.st->count, cb = B.st->count;
+    unsigned act_a = 0, act_b = 0;
+    size_t m = SIZE_MAX, longest = 0;
+    alignas(64) uint64_t lv[16];
+    for (int k = 0; k < 16; k++) {
+        const bool on = (k < 8 ? k < ca : k - 8 < cb) && len[k];
+        lv[k] = on ? len[k] : 0;
+        if (on) { (k < 8 ? act_a : act_b) |= 1u << (k & 7); if (len[k] < m) m = len[k]; if (len[k] > longest) longest = len[k]; }
+    }
+    size_t pos = 0;
+    if (act_a == (1u << ca) - 1u && act_b == (1u << cb) - 1u && (act_a | act_b)) {
+        for (; pos + 4 <= m; pos += 4) {
+            const uint64_t *row = rows + 4 * pos;                // 16 words per four bins
+            _mm_prefetch((const char *)(row + 16 * 16), _MM_HINT_T0);
+            const __m512i ga = _mm512_load_si512((const void *)row), gb = _mm512_load_si512((const void *)(row + 8));
+            step_all(RA, OA, ga);                         step_all(RB, OB, gb);
+            step_all(RA, OA, _mm512_srli_epi64(ga, 16));  step_all(RB, OB, _mm512_srli_epi64(gb, 16));
+            step_all(RA, OA, _mm512_srli_epi64(ga, 32));  step_all(RB, OB, _mm512_srli_epi64(gb, 32));
+            step_all(RA, OA, _mm512_srli_epi64(ga, 48));  step_all(RB, OB, _mm512_srli_epi64(gb, 48));
+        }
+    }
+    // whatever is left (lanes of different length, a pack with idle lanes): one bin at a time, lanes masked by their length
+    const __m512i la = _mm512_load_si512((const void *)lv), lb = _mm512_load_si512((const void *)(lv + 8));
+    for (; pos < longest; pos++) {
+        const uint64_t *row = rows + 16 * (pos >> 2);
+        const __m512i sh = _mm512_set1_epi64((long long)(16 * (pos & 3))), p = _mm512_set1_epi64((long long)pos);
+        const __mmask8 ka = _mm512_cmplt_epu64_mask(p, la), kb = _mm512_cmplt_epu64_mask(p, lb);
+        if (ka) step(RA, OA, _mm512_srlv_epi64(_mm512_load_si512((const void *)row), sh), ka);
+        if (kb) step(RB, OB, _mm512_srlv_epi64(_mm512_load_si512((const void *)(row + 8)), sh), kb);
+    }
+    A.st->L.r = RA;
+    B.st->L.r = RB;
+}
+
 // leftovers of the byte accumulators, then the 4-byte flush of lo (NBLIC.c:576-586)
 NB_TARGET void RangeX8::end(size_t *lens) {
     Lanes &L = st->L;
