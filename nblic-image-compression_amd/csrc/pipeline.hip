@@ -122,6 +122,7 @@ static void locked_free(uint16_t *p) {
 struct CodedBuf { uint16_t *p = nullptr; size_t cap = 0; };        // device; one image's coded bins (QNBLIC: pairs + histograms)
 constexpr size_t kChunkBins = size_t(1) << 20;                     // bins per lane per chunk of the host ring
 constexpr int kCopyStreams = 8;
+constexpr int kRingDepth = 3;                                      // chunks in flight per coder thread: the one being coded + two on their way
 constexpr int kMaxTake = 16;                                       // images one coder thread codes together (two AVX-512 packs)
 
 }  // namespace nblic
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(256) k_interleave16(InterleaveArgs a, uint64_t
 // hardware queue with a group's kernels have their copies stuck behind those kernels.
 struct CoderThread {
     hipStream_t stream = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[kRingDepth] = {};
     uint16_t *ring = nullptr;
     uint64_t *d_rows = nullptr;                          // device: two halves of interleaved rows (k_interleave16's output)
     uint16_t *whole = nullptr; size_t whole_cap = 0;     // pinned; one whole QNBLIC image (its rANS runs last pixel first)
@@ -357,8 +358,8 @@ struct CoderThread {
         if (d_rows) hipFree(d_rows);
         for (auto &e : ev) if (e) hipEventDestroy(e);
     }
-    uint16_t *slot(int half, int lane) { return ring + (size_t(half) * kMaxTake + size_t(lane)) * kChunkBins; }
-    uint64_t *rows(int half) { return reinterpret_cast<uint64_t *>(ring) + size_t(half) * (kChunkBins / 4 * kMaxTake); }   // same bytes as the lanes' slots
+    uint16_t *slot(size_t chunk, int lane) { return ring + (size_t(chunk % kRingDepth) * kMaxTake + size_t(lane)) * kChunkBins; }
+    uint64_t *rows(size_t chunk) { return reinterpret_cast<uint64_t *>(ring) + size_t(chunk % kRingDepth) * (kChunkBins / 4 * kMaxTake); }   // same bytes as the lanes' slots
 };
 
 // Streams `take` images' bins from HBM and codes them: one image with the scalar coder, up to
@@ -366,8 +367,8 @@ struct CoderThread {
 // lens[k] = coder bytes or SIZE_MAX.
 static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size_t *n, int take, uint8_t *const *dst,
                           const size_t *caps, size_t *lens) {
-    if (!t.ring && !(t.ring = locked_alloc(2 * kMaxTake * kChunkBins))) { fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
-    if (take > 1 && !t.d_rows) HIP_OK(hipMalloc((void **)&t.d_rows, 2 * (kChunkBins / 4 * kMaxTake) * sizeof(uint64_t)));
+    if (!t.ring && !(t.ring = locked_alloc(kRingDepth * kMaxTake * kChunkBins))) { fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
+    if (take > 1 && !t.d_rows) HIP_OK(hipMalloc((void **)&t.d_rows, kRingDepth * (kChunkBins / 4 * kMaxTake) * sizeof(uint64_t)));
     size_t n_max = 0;
     for (int k = 0; k < take; k++) n_max = n[k] > n_max ? n[k] : n_max;
     const size_t chunks = (n_max + kChunkBins - 1) / kChunkBins;
@@ -379,7 +380,7 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
     auto lane_of = [&](int k) { return k < na ? k : 8 + (k - na); };
     auto issue = [&](size_t c) -> bool {
         if (take == 1) {                                      // one image: its bins as they are, for the scalar coder
-            HIP_OK(hipMemcpyAsync(t.slot(int(c & 1), 0), dev[0] + c * kChunkBins, chunk_len(c, 0) * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
+            HIP_OK(hipMemcpyAsync(t.slot(c, 0), dev[0] + c * kChunkBins, chunk_len(c, 0) * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
         } else {                                              // a pack pair: interleaved on the GPU, one copy
             InterleaveArgs a{};
             size_t longest = 0;
@@ -389,30 +390,30 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
                 longest = len > longest ? len : longest;
             }
             const uint32_t n_rows = uint32_t((longest + 3) / 4);
-            uint64_t *d = t.d_rows + size_t(c & 1) * (kChunkBins / 4 * kMaxTake);
+            uint64_t *d = t.d_rows + size_t(c % kRingDepth) * (kChunkBins / 4 * kMaxTake);
             if (n_rows) {
                 hipLaunchKernelGGL(k_interleave16, dim3((n_rows * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_rows);
                 HIP_OK(hipGetLastError());
-                HIP_OK(hipMemcpyAsync(t.rows(int(c & 1)), d, size_t(n_rows) * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
+                HIP_OK(hipMemcpyAsync(t.rows(c), d, size_t(n_rows) * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
             }
         }
-        HIP_OK(hipEventRecord(t.ev[c & 1], t.stream));
+        HIP_OK(hipEventRecord(t.ev[c % kRingDepth], t.stream));
         return true;
     };
     if (take > 1) { t.x8.begin(na, dst, caps); t.x8b.begin(nb, dst + na, caps + na); }
     else t.x1.begin(dst[0], caps[0]);
-    if (chunks && !issue(0)) return false;
+    for (size_t c = 0; c + 1 < size_t(kRingDepth) && c < chunks; c++) if (!issue(c)) return false;
     for (size_t c = 0; c < chunks; c++) {
-        if (c + 1 < chunks && !issue(c + 1)) return false;
+        if (c + kRingDepth - 1 < chunks && !issue(c + kRingDepth - 1)) return false;      // its ring slot was consumed one chunk ago
         auto w0 = std::chrono::steady_clock::now();
-        HIP_OK(hipEventSynchronize(t.ev[c & 1]));
+        HIP_OK(hipEventSynchronize(t.ev[c % kRingDepth]));
         t.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         if (take > 1) {
             size_t len[kMaxTake] = {0};
             for (int k = 0; k < take; k++) len[lane_of(k)] = chunk_len(c, k);
-            feed_pair_rows(t.x8, t.x8b, t.rows(int(c & 1)), len);
+            feed_pair_rows(t.x8, t.x8b, t.rows(c), len);
         } else {
-            t.x1.feed(t.slot(int(c & 1), 0), chunk_len(c, 0));
+            t.x1.feed(t.slot(c, 0), chunk_len(c, 0));
         }
     }
     if (take > 1) { t.x8.end(lens); t.x8b.end(lens + na); }
