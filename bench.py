@@ -21,7 +21,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The pipeline keeps 6 group streams + 4 copy streams + 1 serial-engine stream busy.  The HIP runtime
+# The pipeline keeps 6 group streams + 8 copy streams + 1 serial-engine stream busy.  The HIP runtime
 # multiplexes streams onto 4 hardware queues by default, which puts the coder threads' copies
 # behind other groups' kernels; it reads this when it initialises, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -20,7 +20,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-# The batch pipeline keeps 6 group streams + 4 copy streams busy; the HIP runtime multiplexes
+# The batch pipeline keeps 6 group streams + 8 copy streams busy; the HIP runtime multiplexes
 # streams onto 4 hardware queues by default and reads this when it initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
