@@ -120,9 +120,13 @@ static void locked_free(uint16_t *p) {
 }
 
 struct CodedBuf { uint16_t *p = nullptr; size_t cap = 0; };        // device; one image's coded bins (QNBLIC: pairs + histograms)
-constexpr size_t kChunkBins = size_t(1) << 20;                     // bins per lane per chunk of the host ring
+// Bins per lane per chunk of the host ring.  Every chunk costs the GPU two dispatches per thread (the
+// interleave kernel and the copy, which the runtime performs with a blit kernel) that have to find
+// room between the encoder's own kernels: with 1 Mbin chunks the coder threads waited for their
+// next chunk 15-20 % of the time (4.7 Gpx/s), with 4 Mbin chunks 3 % (5.2 Gpx/s).
+constexpr size_t kChunkBins = size_t(1) << 22;
 constexpr int kCopyStreams = 8;
-constexpr int kRingDepth = 3;                                      // chunks in flight per coder thread: the one being coded + two on their way
+constexpr int kRingDepth = 2;                                      // ring slots per coder thread: the chunk being coded + the next one on its way
 constexpr int kMaxTake = 16;                                       // images one coder thread codes together (two AVX-512 packs)
 
 }  // namespace nblic
@@ -193,6 +197,7 @@ struct nblic_amd_ctx {
     std::chrono::steady_clock::time_point t_batch;
     double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_batch).count(); }
     std::vector<hipStream_t> copy_streams;   // shared by the coder threads (device -> host chunk copies)
+    size_t chunk_bins = kChunkBins;          // bins per lane per chunk (NBLIC_AMD_CHUNK_BINS shrinks it, for tests of the chunk boundaries)
     std::vector<CodedBuf> cbufs;
     std::deque<int> free_cbufs;
     int coding = 0;                       // images handed to the GPU whose streams are not finished yet
@@ -366,13 +371,13 @@ struct CoderThread {
 // eight in the lanes of the AVX-512 coder, up to sixteen as two packs in lock-step.
 // lens[k] = coder bytes or SIZE_MAX.
 static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size_t *n, int take, uint8_t *const *dst,
-                          const size_t *caps, size_t *lens) {
+                          const size_t *caps, size_t *lens, size_t chunk_bins) {
     if (!t.ring && !(t.ring = locked_alloc(kRingDepth * kMaxTake * kChunkBins))) { fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
     if (take > 1 && !t.d_rows) HIP_OK(hipMalloc((void **)&t.d_rows, kRingDepth * (kChunkBins / 4 * kMaxTake) * sizeof(uint64_t)));
     size_t n_max = 0;
     for (int k = 0; k < take; k++) n_max = n[k] > n_max ? n[k] : n_max;
-    const size_t chunks = (n_max + kChunkBins - 1) / kChunkBins;
-    auto chunk_len = [&](size_t c, int k) { const size_t off = c * kChunkBins; return off >= n[k] ? size_t(0) : (n[k] - off < kChunkBins ? n[k] - off : kChunkBins); };
+    const size_t chunks = (n_max + chunk_bins - 1) / chunk_bins;                     // chunk_bins <= kChunkBins, the ring's slot size
+    auto chunk_len = [&](size_t c, int k) { const size_t off = c * chunk_bins; return off >= n[k] ? size_t(0) : (n[k] - off < chunk_bins ? n[k] - off : chunk_bins); };
     // two packs in lock-step whenever there is more than one image: a lone pack is bound by the
     // latency of its own dependent chain, a second one rides along almost for free.  Pack a takes
     // the first half of the images (lanes 0..), pack b the rest (lanes 8..).
@@ -380,13 +385,13 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
     auto lane_of = [&](int k) { return k < na ? k : 8 + (k - na); };
     auto issue = [&](size_t c) -> bool {
         if (take == 1) {                                      // one image: its bins as they are, for the scalar coder
-            HIP_OK(hipMemcpyAsync(t.slot(c, 0), dev[0] + c * kChunkBins, chunk_len(c, 0) * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
+            HIP_OK(hipMemcpyAsync(t.slot(c, 0), dev[0] + c * chunk_bins, chunk_len(c, 0) * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
         } else {                                              // a pack pair: interleaved on the GPU, one copy
             InterleaveArgs a{};
             size_t longest = 0;
             for (int k = 0; k < take; k++) {
                 const size_t len = chunk_len(c, k);
-                a.src[lane_of(k)] = dev[k] + c * kChunkBins; a.len[lane_of(k)] = uint32_t(len);
+                a.src[lane_of(k)] = dev[k] + c * chunk_bins; a.len[lane_of(k)] = uint32_t(len);
                 longest = len > longest ? len : longest;
             }
             const uint32_t n_rows = uint32_t((longest + 3) / 4);
@@ -411,7 +416,8 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
         if (take > 1) {
             size_t len[kMaxTake] = {0};
             for (int k = 0; k < take; k++) len[lane_of(k)] = chunk_len(c, k);
-            feed_pair_rows(t.x8, t.x8b, t.rows(c), len);
+            static const bool feed_only = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 128);   // measurement aid: bins reach the host but are not coded
+            if (!feed_only) feed_pair_rows(t.x8, t.x8b, t.rows(c), len);
         } else {
             t.x1.feed(t.slot(c, 0), chunk_len(c, 0));
         }
@@ -499,7 +505,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
         }
         static const bool skip_coding = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 16);   // measurement aid: device side alone
         if (skip_coding) { for (int k = 0; k < take; k++) lens[k] = 0; }
-        else if (!code_streamed(t, src, n, take, dst, caps, lens)) {
+        else if (!code_streamed(t, src, n, take, dst, caps, lens, c->chunk_bins)) {
             c->failed = true;
             hipDeviceSynchronize();
             for (int k = 0; k < take; k++) lens[k] = SIZE_MAX;
@@ -907,6 +913,10 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     // (Measured and rejected: creating the copy streams with the highest stream priority, so that the
     // coder threads' short interleave kernels and copies overtake the encoder's long kernels -- the
     // pipeline drops from 4.9 to 3.1 Gpx/s.)
+    if (const char *cb = getenv("NBLIC_AMD_CHUNK_BINS")) {
+        const size_t v = size_t(atol(cb)) & ~size_t(3);          // a multiple of four: the rows hold four bins per word
+        if (v >= 4096 && v <= kChunkBins) c->chunk_bins = v;
+    }
     c->copy_streams.resize(size_t(n_coders < kCopyStreams ? n_coders : kCopyStreams));
     for (auto &cs : c->copy_streams)
         if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { cs = nullptr; nblic_amd_destroy(c); return nullptr; }

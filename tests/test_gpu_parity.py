@@ -262,15 +262,20 @@ def test_size_limits(pkg, gpu_ctx):
 @pytest.mark.gpu
 def test_sixteen_image_packs_and_chunked_streaming(pkg, oracle):
     """Many images, few coder threads: the coder threads take full 16-image packs (two AVX-512
-    registers in lock-step), stream each image's bins from HBM in 1 Mbin chunks (several images
-    here span 2-3 chunks, all end at different bins) and wait for packs to fill mid-batch.
+    registers in lock-step), stream each image's bins from HBM in chunks (256 Kbin here, so the images
+    span up to a dozen chunks and all end at different bins) and wait for packs to fill mid-batch.
     Every stream must still be the oracle's, byte for byte."""
     rng = np.random.default_rng(3)
     imgs = []
     for k in range(44):
         h, w = int(rng.integers(200, 760)), int(rng.integers(200, 900))
         imgs.append(inputs.make(inputs.CONTENTS[k % len(inputs.CONTENTS)], h, w) if k % 4 else inputs.syn1(h, w, seed=k + 1))
-    ctx = pkg.Context(device=0, n_slots=16, n_coders=2, n_groups=4, n_host_buffers=64)
+    import os
+    os.environ["NBLIC_AMD_CHUNK_BINS"] = "262144"               # the pipeline's 4 Mbin chunks would swallow these images whole
+    try:
+        ctx = pkg.Context(device=0, n_slots=16, n_coders=2, n_groups=4, n_host_buffers=64)
+    finally:
+        del os.environ["NBLIC_AMD_CHUNK_BINS"]
     try:
         got = ctx.encode_batch(imgs)
         again = ctx.encode_batch(imgs[:5])                      # a short batch right after: singles
