@@ -102,19 +102,31 @@ bool size_ok(int h, int w, long max_px) {                                       
 // that will read them (so they sit on its NUMA node), then page-locked in place.  hipHostMalloc'ed
 // memory reads 14-18 % slower from these threads (measured: 1650 vs 1950 Mbins/s through the
 // sixteen-lane coder, tools/pinned_coder_bench.py).
+static std::mutex g_locked_m;
+static std::vector<void *> g_from_runtime;                          // the few buffers that had to come from hipHostMalloc instead
+
 static uint16_t *locked_alloc(size_t words) {
-    if (getenv("NBLIC_AMD_HOSTMALLOC")) { void *q = nullptr; return hipHostMalloc(&q, words * sizeof(uint16_t), hipHostMallocDefault) == hipSuccess ? static_cast<uint16_t *>(q) : nullptr; }
     const size_t bytes = (words * sizeof(uint16_t) + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
-    void *p = aligned_alloc(size_t(2) << 20, bytes);
-    if (!p) return nullptr;
-    madvise(p, bytes, MADV_HUGEPAGE);
-    memset(p, 0, bytes);
-    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { free(p); return nullptr; }
-    return static_cast<uint16_t *>(p);
+    if (!getenv("NBLIC_AMD_HOSTMALLOC")) {
+        if (void *p = aligned_alloc(size_t(2) << 20, bytes)) {
+            madvise(p, bytes, MADV_HUGEPAGE);
+            memset(p, 0, bytes);
+            if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) return static_cast<uint16_t *>(p);
+            free(p);
+        }
+    }
+    void *q = nullptr;                                              // registration refused (or disabled): the runtime's own pinned memory
+    if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    { std::lock_guard<std::mutex> l(g_locked_m); g_from_runtime.push_back(q); }
+    return static_cast<uint16_t *>(q);
 }
 static void locked_free(uint16_t *p) {
     if (!p) return;
-    if (getenv("NBLIC_AMD_HOSTMALLOC")) { hipHostFree(p); return; }
+    {
+        std::lock_guard<std::mutex> l(g_locked_m);
+        auto it = std::find(g_from_runtime.begin(), g_from_runtime.end(), static_cast<void *>(p));
+        if (it != g_from_runtime.end()) { g_from_runtime.erase(it); hipHostFree(p); return; }
+    }
     hipHostUnregister(p);
     free(p);
 }
