@@ -1,0 +1,199 @@
+// tests/host_harness.cpp -- TEST HARNESS (host only): a scalar, fused NBLIC encoder put together
+// from the PRODUCT's host-compilable headers (csrc/model.h, csrc/lsq_f64.h), so that the integer
+// model functions and the double-carried least-squares arithmetic the GPU kernels use can be
+// checked against the oracle without a GPU (tests/test_host_logic.py).  It emits the coded-bin
+// stream (prob | bin << 15 per bin); the test turns that into bytes with the product's host range
+// coder (nblic_amd_range_code).  Not part of the product library; never a fallback for it.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../nblic-image-compression_amd/csrc/lsq_f64.h"
+#include "../nblic-image-compression_amd/csrc/model.h"
+
+using namespace nblic;
+typedef long long i64;
+typedef unsigned long long u64;
+
+namespace {
+
+i64 mulw(i64 a, i64 b) { return i64(u64(a) * u64(b)); }
+i64 abs64(i64 v) { return v < 0 ? -v : v; }
+
+// plain-integer solve of the augmented system M[n][n+1] (NBLIC.c:112-161, :233-236): the fallback
+bool solve_int(int n, const double Md[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, i64 *px) {
+    i64 M[lsq::kMaxN][lsq::kMaxN + 1];
+    for (int i = 0; i < n; i++) for (int j = 0; j <= n; j++) M[i][j] = i64(Md[i][j]);
+    for (int k = 0; k + 1 < n; k++) {
+        int piv = k;
+        for (int i = k + 1; i < n; i++) if (abs64(M[i][k]) > abs64(M[piv][k])) piv = i;
+        if (piv != k) for (int j = 0; j <= n; j++) { i64 t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+        const i64 d = M[k][k];
+        if (d == 0) return false;
+        for (int i = k + 1; i < n; i++) {
+            const i64 l = M[i][k];
+            for (int j = k + 1; j <= n; j++) M[i][j] -= mulw(M[k][j], l) / d;
+        }
+    }
+    for (int k = n - 1; k > 0; k--) {
+        const i64 d = M[k][k];
+        if (d == 0) return false;
+        for (int i = 0; i < k; i++) M[i][n] -= mulw(M[k][n], M[i][k]) / d;
+    }
+    i64 p = i64(kMid) << lsq::kFb1;
+    for (int k = 0; k < n; k++) { const i64 d = M[k][k]; p += (mulw(mulw(M[k][n], vn[k]), 1 << lsq::kFb2) + (d >> 1)) / d; }
+    *px = p;
+    return true;
+}
+
+// the same solve in doubles, organised the way the GPU does it: rows stay where they are and carry
+// a position; the pivot is the candidate with the largest |entry|, ties to the smallest position
+bool solve_f64(int n, double M[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, lsq::Guard &g, double *px) {
+    int pos[lsq::kMaxN], at[lsq::kMaxN];
+    double diag[lsq::kMaxN];
+    for (int i = 0; i < n; i++) { pos[i] = i; at[i] = i; for (int j = 0; j <= n; j++) g.entry = fmax(g.entry, fabs(M[i][j])); }
+    for (int k = 0; k + 1 < n; k++) {
+        int c = -1; double best = -1.0;
+        for (int r = 0; r < n; r++) {
+            if (pos[r] < k) continue;
+            const double key = fabs(M[r][k]) * 256.0 + double((15 - pos[r]) * 16 + r);
+            if (key > best) { best = key; c = r; }
+        }
+        const int a = at[k];                                   // row that sat at position k
+        at[pos[c]] = a; pos[a] = pos[c]; pos[c] = k; at[k] = c;
+        const double d = M[c][k];
+        diag[c] = d;
+        if (d == 0.0) return false;
+        const double rd = 1.0 / d;
+        for (int r = 0; r < n; r++) {
+            if (pos[r] <= k) continue;
+            const double l = M[r][k];
+            for (int j = k + 1; j <= n; j++) {
+                M[r][j] -= lsq::muldiv_trunc(M[c][j], l, d, rd, g);
+                g.entry = fmax(g.entry, fabs(M[r][j]));
+            }
+        }
+    }
+    diag[at[n - 1]] = M[at[n - 1]][n - 1];
+    for (int k = n - 1; k > 0; k--) {
+        const int c = at[k];
+        const double d = diag[c];
+        if (d == 0.0) return false;
+        const double rd = 1.0 / d, bk = M[c][n];
+        for (int r = 0; r < n; r++) {
+            if (pos[r] >= k) continue;
+            M[r][n] -= lsq::muldiv_trunc(bk, M[r][k], d, rd, g);
+            g.entry = fmax(g.entry, fabs(M[r][n]));
+        }
+    }
+    double p = double(kMid << lsq::kFb1);
+    for (int r = 0; r < n; r++) p += lsq::term(M[r][n], vn[pos[r]], diag[r], g);
+    *px = p;
+    return true;
+}
+
+}  // namespace
+
+extern "C" long hh_model_encode(const uint8_t *img_in, uint8_t *recon, int h, int w, int near, int effort, uint16_t *coded, long cap,
+                                long *fallbacks) {
+    const int n = lsq::order_of(effort), m = lsq::vec_len(n);
+    const int k_step = k_step_for_near(near);
+    std::vector<int> ctx(kContexts, 0);
+    std::vector<Counter> tree(size_t(kLevels) * kTreeNodes, Counter{kWeightOne, kWeightOne});
+    struct Mapper { int count[kMapSyms]; uint8_t rank_of[kMapSyms], sym_at[kMapSyms]; };
+    std::vector<Mapper> maps(512);
+    for (auto &mp : maps) for (int s = 0; s < kMapSyms; s++) { mp.count[s] = 2 * (kMapSyms - 1 - s); mp.rank_of[s] = mp.sym_at[s] = uint8_t(s); }
+    std::vector<double> B(size_t(n ? w : 0) * m, 0.0), F(size_t(n ? w : 0) * m, 0.0), E(m, 0.0);
+    memcpy(recon, img_in, size_t(h) * w);
+    long n_bins = 0, n_fallback = 0;
+    int bias = lsq::kBiasInit;
+    auto pix = [&](int r, int c) { return int(recon[size_t(r) * w + c]); };
+    for (int i = 0; i < h; i++) {
+        int err = 0;
+        if (n) {
+            for (int k = 0; k < m; k++) E[k] = 0.0;
+            for (int k = 0; k < m; k++) {                     // NBLIC.c:186-204
+                double carry = 0.0;
+                for (int j = w - 1; j >= 0; j--) { const double f = carry + B[size_t(j) * m + k]; F[size_t(j) * m + k] = f; carry = lsq::decay_k(f, k); }
+            }
+        }
+        for (int j = 0; j < w; j++) {
+            const Taps t = sample_taps(pix, w, i, j);
+            int vn[lsq::kMaxN] = {t.a - kMid, t.b - kMid, t.c - kMid, t.d - kMid, t.e - kMid, t.f - kMid, t.t - kMid, t.h - kMid, t.q - kMid, t.g - kMid};
+            int b1 = 0, b2 = 0, px0;
+            i64 p1 = 0, p2 = 0;
+            bool ok1 = false, ok2 = false;
+            double *Bj = n ? &B[size_t(j) * m] : nullptr, *Fj = n ? &F[size_t(j) * m] : nullptr;
+            if (n) {
+                lsq::bias_pair(bias, b1, b2);
+                for (int s = 0; s < 2; s++) {
+                    const int bs = s ? b2 : b1;
+                    double M[lsq::kMaxN][lsq::kMaxN + 1], Mi[lsq::kMaxN][lsq::kMaxN + 1];
+                    for (int r = 0; r < n; r++) {
+                        for (int c = 0; c < n; c++) M[r][c] = E[1 + n + r * n + c] + Fj[1 + n + r * n + c] + (r == c ? double(bs * n) : 0.0);
+                        M[r][n] = E[1 + r] + Fj[1 + r] + double(bs) * double(1 << lsq::kFb3);
+                    }
+                    memcpy(Mi, M, sizeof M);
+                    lsq::Guard g;
+                    double pd = 0.0;
+                    bool ok = solve_f64(n, M, vn, g, &pd);
+                    i64 p = i64(pd);
+                    if (!g.ok()) { n_fallback++; ok = solve_int(n, Mi, vn, &p); }
+                    p = p < 0 ? 0 : (p > (i64(kMaxVal) << lsq::kFb1) ? (i64(kMaxVal) << lsq::kFb1) : p);
+                    if (s) { ok2 = ok; p2 = p; } else { ok1 = ok; p1 = p; }
+                }
+            }
+            if (ok1) px0 = int((p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1);
+            else { px0 = predict(t); p1 = i64(px0) << lsq::kFb1; }
+            const Level L = quantise(activity(t, err));
+            const int adr = context_address(t, L.qu, px0);
+            const int v = ctx[adr];
+            const int sign = bias_sign(v), px = bias_apply(v, px0);
+            Mapper &mp = maps[size_t(px * 2 + sign)];
+            const int y = residual_to_symbol(pix(i, j), px, sign, near);
+            walk_symbol(k_step, L.qu, L.qv, y < kMapSyms ? int(mp.rank_of[y]) : y, [&](int qu, int qv, int node, int bin) {
+                Counter &cu = tree[size_t(qu) * kTreeNodes + node], &cv = tree[size_t(qv) * kTreeNodes + node];
+                const int prob = mix_prob(counter_p1(cu.c0, cu.c1), counter_p1(cv.c0, cv.c1), L.qw);
+                if (n_bins < cap) coded[n_bins] = pack_coded(prob, bin);
+                n_bins++;
+                counter_add(cu, bin, kWeightOne - L.qw);
+                counter_add(cv, bin, L.qw);
+                return bin;
+            });
+            if (y < kMapSyms) {                               // NBLIC.c:497-523
+                const int z = mp.rank_of[y];
+                mp.count[z]++;
+                if (z > 0 && mp.count[z - 1] < mp.count[z]) {
+                    const int other = mp.sym_at[z - 1], c = mp.count[z];
+                    mp.count[z] = mp.count[z - 1]; mp.count[z - 1] = c;
+                    mp.sym_at[z] = uint8_t(other); mp.sym_at[z - 1] = uint8_t(y);
+                    mp.rank_of[y] = uint8_t(z - 1); mp.rank_of[other] = uint8_t(z);
+                }
+            }
+            const int xr = symbol_to_pixel(y, px, sign, near);
+            recon[size_t(i) * w + j] = uint8_t(xr);
+            err = clip_err(xr, px0);
+            ctx[adr] = bias_update(v, err);
+            if (n) {                                          // NBLIC.c:882-893, :242-283
+                const i64 xq = i64(xr) << lsq::kFb1;
+                const double s_curr = double(abs64(p1 - xq));
+                const double s_sum = (E[0] + Fj[0]) + floor(s_curr * double(lsq::kDecayS) / double(lsq::kDecayS - 1));
+                const double s = lsq::sample_weight(s_sum), rs = 1.0 / s;
+                const int xc = xr - kMid;
+                for (int k = 0; k < m; k++) {
+                    double sample;
+                    if (k == 0) sample = s_curr;
+                    else if (k <= n) sample = lsq::sample_entry(xc * vn[k - 1], lsq::kScaleB, s, rs);
+                    else { const int r = (k - 1 - n) / n, c = (k - 1 - n) - r * n; sample = lsq::sample_entry(vn[r] * vn[c], lsq::kScaleA, s, rs); }
+                    const double b = lsq::decay_k(Bj[k], k) + sample;
+                    Bj[k] = b;
+                    E[k] = lsq::decay_k(E[k], k) + b;
+                }
+                if (ok1 && ok2) bias = (abs64(p1 - xq) > abs64(p2 - xq)) ? b2 : b1;
+            }
+        }
+    }
+    if (fallbacks) *fallbacks = n_fallback;
+    return n_bins;
+}
