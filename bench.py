@@ -38,17 +38,28 @@ def cpu_baseline(frames, reps_budget_s=12.0):
     else:
         o = Oracle()
         enc, kind = (lambda im, n, e: o.encode(im, n, e)), "port"
-    px, t_total, used = 0, 0.0, 0
+    px, t_total, used, streams = 0, 0.0, 0, []
     for f in frames:
         t0 = time.perf_counter()
-        enc(f, 0, 1)
+        streams.append(enc(f, 0, 1)[0])
         t_total += time.perf_counter() - t0
         px += f.size
         used += 1
         if t_total > reps_budget_s:
             break
     return {"value": round(px / t_total / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": kind,
-            "sample": f"{used} of the batch's {frames[0].shape[0]}x{frames[0].shape[1]} SYN-1 frames, -n0 -e1, one thread"}
+            "sample": f"{used} of the batch's {frames[0].shape[0]}x{frames[0].shape[1]} SYN-1 frames, -n0 -e1, one thread"}, streams, enc
+
+
+def verify_frames(enc, make_frame, indices, got, workers):
+    """Byte-for-byte check of the GPU streams of the frames `indices` against the CPU encoder (outside the
+    timed region; the C encoders release the GIL, so `workers` threads run side by side)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(k):
+        return enc(make_frame(k), 0, 1)[0] == got(k)
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        return list(ex.map(one, indices))
 
 
 def profiled_traffic(kernel, images_per_launch):
@@ -73,6 +84,50 @@ def profiled_traffic(kernel, images_per_launch):
     return None
 
 
+def launch_ranks(n_gpus, backend):
+    """`python bench.py --gpus N` started directly (no WORLD_SIZE in the environment): this process becomes
+    the launcher.  It touches neither torch nor the GPU; it starts N children of this same script, one
+    rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would set them),
+    lets rank 0 write the JSON line to our stdout, and exits non-zero if any rank does."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for r, pr in enumerate(procs):
+        code = pr.wait()
+        if code != 0:
+            print(f"[bench] rank {r} exited with {code}", file=sys.stderr)
+            rc = rc or code or 1
+    sys.exit(rc)
+
+
+def host_description():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    toggles = {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "NBLIC_AMD_HOSTMALLOC", "NBLIC_AMD_CHUNK_BINS", "NBLIC_AMD_DBG",
+                                          "NBLIC_AMD_NO_SIMD", "NBLIC_AMD_DEVICE", "NBLIC_BENCH_DEVICE") if k in os.environ}
+    return {"cpu_model": model, "cpus_available": cpus, "cpus_total": os.cpu_count(), "env": toggles}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,7 +148,16 @@ def main():
                          "run of steps, inside the timed region, instead of once per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 path be rehearsed with every rank on one GPU")
+    ap.add_argument("--launch-check", action="store_true", help="no GPU work: every rank joins a gloo group, rank 0 prints how many ranks it saw (tests the --gpus N launcher on a CPU-only box)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed extra measurements (single frame, 8-frame batch, host inputs)")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        launch_ranks(args.gpus, args.dist_backend)           # does not return
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a mislabelled run", file=sys.stderr)
+        sys.exit(2)
 
     import numpy as np
     import torch
@@ -102,6 +166,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.launch_check:
+        seen = 1
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            t = torch.tensor([1], dtype=torch.int64)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "local_rank": local_rank}), flush=True)
+        return
     gpu = int(os.environ.get("NBLIC_BENCH_DEVICE", local_rank))       # rehearsal: all ranks on one GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -156,8 +232,11 @@ def main():
 
     last = {}
 
+    all_lens = []
+
     def exchange(lens, which):
         last["lens"], last["outs"] = lens, out_sets[which]
+        all_lens.append(np.array(lens, copy=True))
         if world > 1:                                   # the one exchange of the path: streams -> rank 0 (stay in HBM)
             for k0 in range(0, B, GATHER_CHUNK):
                 k1 = min(B, k0 + GATHER_CHUNK)
@@ -193,6 +272,7 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup)
+    del all_lens[:]
     fence()
     t0 = time.perf_counter()
     run(args.steps)
@@ -221,20 +301,72 @@ def main():
         gathered_ok = (len(payloads) == world and all(int(l.sum()) == p.numel() for p, l in zip(payloads, lens_all)) and
                        hashlib.sha256(payloads[0][: int(lens_all[0][0])].cpu().numpy().tobytes()).hexdigest() ==
                        hashlib.sha256(last["outs"][k0][: int(lens[k0])].tobytes()).hexdigest())
-    bit_exact = None
+    # ---- untimed extra legs: one frame alone, the 8-frame batch north_star names, host inputs --------
+    extra = {}
+    if not args.no_extra_legs:
+        def timed_call(fn):
+            fence()
+            t0 = time.perf_counter()
+            fn()
+            fence()
+            d = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([d], dtype=torch.float64, device=comm_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                d = float(tt.item())
+            return d
+        one = max(1, 8 // world)                                     # 8 frames over the whole job: 8 / N per GPU
+        d8 = timed_call(lambda: ctx.encode_ptrs(ptrs[:one], shapes[:one], not args.host_inputs, outs[:one]))
+        extra["batch8_Mpixel_per_s"] = round(one * world * H * W / d8 / 1e6, 2)
+        extra["batch8_frames_per_gpu"] = one
+        if world == 1:
+            d1 = min(timed_call(lambda: ctx.encode_ptrs(ptrs[:1], shapes[:1], not args.host_inputs, outs[:1])) for _ in range(3))
+            extra["single_frame_ms"] = round(d1 * 1e3, 2)
+            if not args.host_inputs:                                 # SURVEY 8(d)'s quantity: every frame uploaded over PCIe inside the region
+                nb = min(B, 128)
+                host = [pkg.syn1(H, W, seed=rank * B + k + 1) for k in range(nb)]
+                dh = timed_call(lambda: ctx.encode_ptrs([f.ctypes.data for f in host], shapes[:nb], False, outs[:nb]))
+                extra["pcie_inclusive_Mpixel_per_s"] = round(nb * H * W / dh / 1e6, 2)
+                extra["pcie_inclusive_frames"] = nb
+                del host
+
+    # ---- correctness of what was timed (outside the timed region) ------------------------------------
+    bit_exact, checks = None, {}
     if rank == 0:
         try:
             with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
                 m = json.load(f)["large"].get(f"syn1s1_{H}x{W}_n0_e1")
             if m:
-                s = last["outs"][0][: int(lens[0])].tobytes()
-                bit_exact = (len(s) == m["len"] and hashlib.sha256(s).hexdigest() == m["sha256"])
+                s0 = last["outs"][0][: int(lens[0])].tobytes()
+                checks["frame0_golden_sha"] = (len(s0) == m["len"] and hashlib.sha256(s0).hexdigest() == m["sha256"])
         except OSError:
             pass
+        checks["every_step_same_lengths"] = all(np.array_equal(l, all_lens[0]) for l in all_lens) and len(all_lens) == args.steps
+        if args.overlap_steps and args.steps >= 2:                   # the last two steps' slabs, byte for byte
+            la = torch.from_numpy(np.asarray(lens)).clamp(max=cap)
+            same = True
+            for k in range(B):
+                n = int(la[k])
+                same = same and bool(torch.equal(slabs[0][k, :n], slabs[1][k, :n]))
+            checks["last_two_steps_identical"] = same
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, ref_streams, enc = cpu_baseline(frames)
+        ok = [ref_streams[k] == last["outs"][k][: int(lens[k])].tobytes() for k in range(len(ref_streams))]
+        spread = [k for k in sorted({(B * j) // 16 + (j % 16) for j in range(1, 16)}) if len(ref_streams) <= k < B]   # other packs, other lanes
+        ok += verify_frames(enc, lambda k: pkg.syn1(H, W, seed=rank * B + k + 1), spread,
+                            lambda k: last["outs"][k][: int(lens[k])].tobytes(), min(16, cpus))
+        checks["frames_vs_cpu_encoder"] = f"{sum(ok)}/{len(ok)}"
+        checks["frames_checked"] = list(range(len(ref_streams))) + spread
+        checks["all_frames_vs_cpu_ok"] = all(ok)
+    if rank == 0:
+        bit_exact = all(v for k, v in checks.items() if isinstance(v, bool))
 
     if rank == 0:
         total_px = float(H) * W * B * world * args.steps
         value = total_px / dt / 1e6
+        steps_counted = args.steps if args.overlap_steps else 1      # the library's counters run over all overlapped steps
         line = {
             "metric": "Mpixel/s encode (bit-exact) 4096x4096 gray -e1 lossless",
             "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -243,21 +375,34 @@ def main():
             "config": {"workload": f"{B} x {H}x{W} SYN-1 gray frames per GPU per step, -n0 -e1, inputs resident in HBM" + (", steps submitted back to back (two in flight)" if args.overlap_steps else "")
                        if not args.host_inputs else f"{B} x {H}x{W} SYN-1 frames per GPU per step, -n0 -e1, host inputs (PCIe-inclusive)",
                        "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "coded_bin_buffers_in_hbm": host_buffers, "steps_overlapped": bool(args.overlap_steps),
-                       "parallelism": f"image-per-GPU x{world}, RCCL gather of streams" if world > 1 else "single GPU"},
-            "bit_exact": bit_exact, "gathered_ok": gathered_ok,
+                       "parallelism": f"image-per-GPU x{world}, RCCL gather of streams" if world > 1 else "single GPU",
+                       "host": host_description()},
+            "bit_exact": bit_exact, "bit_exact_checks": checks, "gathered_ok": gathered_ok,
             "bits_per_pixel": round(8.0 * float(np.mean(lens)) / (H * W), 4),
-            "bins_per_pixel": round(bins / (H * W * B * (args.steps if args.overlap_steps else 1)), 3),   # the library's counters run over all overlapped steps
+            "bins_per_pixel": round(bins / (H * W * B * steps_counted), 3),
             "host_coder_Mbins_per_s_per_thread": round(bins / coder_s / 1e6, 1) if coder_s > 0 else None,
+            # the device -> host feed of the host coder stage: 2 bytes per coded bin over PCIe (spec 63 GB/s)
+            "d2h_bytes_per_bin": 2, "d2h_GB_per_s": round(bins / steps_counted * args.steps * 2 / dt / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": profiled_traffic(dom, imgs_per_launch),
                          "launch_ms": round(per_launch[dom], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                          "images_per_launch": imgs_per_launch},
+            "s1_roofline": {"kernel": "k_predict", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                            "launch_ms": round(per_launch.get("k_predict", 0.0), 4),
+                            "algorithmic_bytes_per_launch": int(5 * H * W * imgs_per_launch),      # 1 B/px read + its 4 B/px record written
+                            "achieved": round(5 * H * W * imgs_per_launch / (per_launch["k_predict"] * 1e-3) / 1e9, 2) if per_launch.get("k_predict") else None,
+                            "frac": round(5 * H * W * imgs_per_launch / (per_launch["k_predict"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if per_launch.get("k_predict") else None},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(frames)
-            line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 2)
+        line.update(extra)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 2)
         print(json.dumps(line), flush=True)
+        if bit_exact is False:
+            print("[bench] a stream differs from the CPU encoder / golden hash / previous step", file=sys.stderr)
+            ctx.close()
+            sys.exit(3)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

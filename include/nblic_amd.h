@@ -105,8 +105,35 @@ int nblic_amd_qencode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned cha
                             const int *heights, const int *widths, uint16_t *const *outs, const size_t *out_caps_words,
                             long *out_len_words);
 
+/* Any mode, many images: the batch form of NBLICcompress (src/NBLIC.h:54, src/NBLIC.c:749-908, :915).
+ * nears[k] / efforts[k] : image k's -n / -e, clamped to [0,9] / [1,3] exactly as the reference clamps them
+ *                  (either array may be NULL: 0 / 1).  -n0 -e1 images take the staged pipeline; every other
+ *                  mode is raster-serial in its prediction (reconstructed neighbours, least-squares
+ *                  statistics), so its model stage runs ONE WAVE PER IMAGE with all images of the batch side
+ *                  by side -- size the context (n_groups x group_size) for the number of images you want in
+ *                  flight -- and its entropy stages on the same parallel kernels and host coder threads.
+ * recons        : NULL, or per image NULL / a host buffer of h*w bytes that receives the reconstruction the
+ *                  reference leaves in p_img (NBLIC.c:876); may be the (host) input plane itself.
+ * Everything else as nblic_amd_encode_batch.  returns 0 / -1.                                        */
+int nblic_amd_encode_batch_modes(nblic_amd_ctx *ctx, int n_images, const unsigned char *const *imgs, int imgs_on_device,
+                                 const int *heights, const int *widths, const int *nears, const int *efforts,
+                                 unsigned char *const *outs, const size_t *out_caps, long *out_lens,
+                                 unsigned char *const *recons);
+
+/* The batch form of NBLICdecompress / QNBLICdecompress (src/NBLIC.h:72, src/QNBLIC.h:16; the codec is told
+ * from the magic like src/NBLIC_main.c:223-226 does): n_images streams decoded side by side, one wave each.
+ * streams[k] / stream_lens[k] : the stream and its length in BYTES (unlike the reference ABI, which takes none).
+ * imgs[k] / img_caps[k]       : host buffer for the plane and its size in bytes.
+ * heights / widths / nears / efforts : outputs parsed from the headers (QNBLIC: near = effort = 0).
+ * status[k]                   : 0, or -1 for that stream (bad header, plane too large, stream exhausted).
+ * returns 0 when every stream decoded, -1 otherwise.                                                 */
+int nblic_amd_decode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned char *const *streams, const size_t *stream_lens,
+                           unsigned char *const *imgs, const size_t *img_caps, int *heights, int *widths, int *nears,
+                           int *efforts, int *status);
+
 /* Opt-in: raise the pixel-count limit above NBLIC_MAX_IMG_SIZE for this context (config 5 of
- * BASELINE.json exceeds the reference's own limit).  0 restores the reference limit.       */
+ * BASELINE.json exceeds the reference's own limit, src/NBLIC.h:31).  0 restores the reference limit.
+ * ctx == NULL addresses the context behind the drop-in entry points of section 1.                   */
 void nblic_amd_set_max_pixels(nblic_amd_ctx *ctx, long max_pixels);
 
 /* Per-kernel device times of the LAST nblic_amd_encode_batch: one HIP event in front of every
@@ -156,6 +183,10 @@ int nblic_amd_range_code_multi(const uint16_t *const *coded, const size_t *n, in
  * can be checked without a GPU.  Returns 0, or -1 for count outside 1..16 or chunk == 0.        */
 int nblic_amd_range_code_chunked(const uint16_t *const *coded, const size_t *n, int count, unsigned char *const *outs,
                                  const size_t *caps, size_t *lens, size_t chunk);
+
+/* Device self-test of the serial kernels' arithmetic: the double-carried truncating divisions of the
+ * least-squares predictor against 64-bit integer division on 65536 operand triples.  0 = pass.   */
+int nblic_amd_serial_selftest(nblic_amd_ctx *ctx);
 
 const char *nblic_amd_version(void);
 

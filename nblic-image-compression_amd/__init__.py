@@ -37,6 +37,7 @@ EXPORTS = (
     "NBLICcompress", "NBLICdecompress", "QNBLICcompress", "QNBLICdecompress", "QNBLICcompressMultiThread",
     "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_encode_batch_begin", "nblic_amd_encode_batch_end", "nblic_amd_qencode_batch", "nblic_amd_set_max_pixels",
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
+    "nblic_amd_encode_batch_modes", "nblic_amd_decode_batch", "nblic_amd_serial_selftest",
     "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_range_code_chunked", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
 )
 
@@ -90,6 +91,14 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_qencode_batch.restype = C.c_int
     lib.nblic_amd_qencode_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, ip, ip,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
+    lib.nblic_amd_encode_batch_modes.restype = C.c_int
+    lib.nblic_amd_encode_batch_modes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, ip, ip, ip, ip,
+                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_long), C.POINTER(C.c_void_p)]
+    lib.nblic_amd_decode_batch.restype = C.c_int
+    lib.nblic_amd_decode_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_size_t), ip, ip, ip, ip, ip]
+    lib.nblic_amd_serial_selftest.restype = C.c_int
+    lib.nblic_amd_serial_selftest.argtypes = [C.c_void_p]
     lib.nblic_amd_set_max_pixels.restype = None
     lib.nblic_amd_set_max_pixels.argtypes = [C.c_void_p, C.c_long]
     lib.nblic_amd_enable_timing.restype = None
@@ -159,6 +168,11 @@ def decompress(stream: bytes) -> Optional[Tuple[np.ndarray, int, int]]:
     if rc != 0:
         return None
     return img[:hh.value, :ww.value], n.value, e.value
+
+
+def set_default_max_pixels(n: int) -> None:
+    """Opt-in pixel limit of the context behind the drop-in operators (``nblic_amd_set_max_pixels(NULL, n)``)."""
+    load_library().nblic_amd_set_max_pixels(None, n)
 
 
 def syn1(h: int, w: int, seed: int = 1) -> np.ndarray:
@@ -269,6 +283,51 @@ class Context:
 
     def selftest(self) -> int:
         return self.lib.nblic_amd_selftest(self.handle)
+
+    def serial_selftest(self) -> int:
+        return self.lib.nblic_amd_serial_selftest(self.handle)
+
+    def encode_modes(self, imgs: Sequence[np.ndarray], nears: Sequence[int], efforts: Sequence[int], want_recon: bool = True):
+        """Any-mode batch encode (``nblic_amd_encode_batch_modes``): per image (near, effort).  Returns
+        (streams, reconstructions or None)."""
+        planes = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        k = len(planes)
+        outs = [np.empty(out_capacity(*p.shape), np.uint8) for p in planes]
+        recs = [np.empty_like(p) for p in planes] if want_recon else None
+        ip_ = (C.c_void_p * k)(*[C.c_void_p(p.ctypes.data) for p in planes])
+        hs = (C.c_int * k)(*[p.shape[0] for p in planes])
+        ws = (C.c_int * k)(*[p.shape[1] for p in planes])
+        nn = (C.c_int * k)(*[int(v) for v in nears])
+        ee = (C.c_int * k)(*[int(v) for v in efforts])
+        op = (C.c_void_p * k)(*[C.c_void_p(o.ctypes.data) for o in outs])
+        caps = (C.c_size_t * k)(*[o.size for o in outs])
+        lens = (C.c_long * k)()
+        rp = (C.c_void_p * k)(*[C.c_void_p(r.ctypes.data) for r in recs]) if want_recon else None
+        if self.lib.nblic_amd_encode_batch_modes(self.handle, k, ip_, 0, hs, ws, nn, ee, op, caps, lens, rp) != 0:
+            raise RuntimeError(f"nblic_amd_encode_batch_modes failed (lengths {list(lens)[:8]}...)")
+        return [o[: lens[i]].tobytes() for i, o in enumerate(outs)], recs
+
+    def decode_batch(self, streams: Sequence[bytes]):
+        """Batch decode of NBLIC / QNBLIC streams (``nblic_amd_decode_batch``).  Returns a list of
+        (image, near, effort) or None per stream."""
+        k = len(streams)
+        bufs = [np.frombuffer(bytes(s), np.uint8).copy() for s in streams]
+        dims = []
+        for b in bufs:
+            if b.size >= 16 and bytes(b[:8]) == b"NBLIC0.3":
+                dims.append(((int(b[9]) << 8) | int(b[10]), (int(b[11]) << 8) | int(b[12])))
+            elif b.size >= 8 and bytes(b[:4]) == b"Q0.2":
+                dims.append((int(b[4]) | (int(b[5]) << 8), int(b[6]) | (int(b[7]) << 8)))
+            else:
+                dims.append((1, 1))
+        imgs = [np.zeros((max(h, 1), max(w, 1)), np.uint8) for (h, w) in dims]
+        sp = (C.c_void_p * k)(*[C.c_void_p(b.ctypes.data) for b in bufs])
+        sl = (C.c_size_t * k)(*[b.size for b in bufs])
+        op = (C.c_void_p * k)(*[C.c_void_p(i.ctypes.data) for i in imgs])
+        caps = (C.c_size_t * k)(*[i.size for i in imgs])
+        hs, ws, nn, ee, st = ((C.c_int * k)() for _ in range(5))
+        self.lib.nblic_amd_decode_batch(self.handle, k, sp, sl, op, caps, hs, ws, nn, ee, st)
+        return [None if st[i] != 0 else (imgs[i][: hs[i], : ws[i]], nn[i], ee[i]) for i in range(k)]
 
     def enable_timing(self, on: bool = True):
         self.lib.nblic_amd_enable_timing(self.handle, int(on))

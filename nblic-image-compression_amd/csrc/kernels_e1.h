@@ -61,6 +61,8 @@ struct E1Job {
     uint32_t n_ev;       // bins (known after the front half)
     SegPlan pe;          // partition plan over bins
     int dbg;             // timing experiments only (NBLIC_AMD_DBG); 0 in normal operation
+    int near, k_step;    // serial modes only (the staged -e1 kernels use the lossless constants 0 and 3)
+    uint64_t ktab;       // model.h level_shift_table(k_step)
 };
 
 // One HIP event before every kernel launch (and one after the last): interval k is exactly
@@ -85,7 +87,12 @@ static const char *const kE1StageNames[kE1Kernels] = {
 int e1_selftest(hipStream_t s);     // 0 = DPP wave scan agrees with the shuffle scan
 // d_jobs: device copy of h_jobs[0..n_jobs).  The host copy is only read to size the grids.
 void e1_launch_front(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm);
-void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm);
+void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm, bool general = false);
+// serial modes (near > 0, efforts 2/3): model state init, then -- after the caller has run the serial
+// model stage (serial_engine.h) that leaves rec1 and px | sign per pixel -- the re-mapper partition,
+// the re-mapper chains and the bin counts; e1_launch_back(..., general = true) finishes the job
+void e1_launch_init(const E1Job *d_jobs, int n_jobs, hipStream_t s);
+void e1_launch_front_pre(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s);
 // QNBLIC (effort 0) model stage for a group: leaves level | symbol << 8 per pixel in `pxs` and the
 // 12 x 256 histograms in `qhist`; the entropy stage (normalise, histogram code, rANS) is host work.
 void q_launch_model(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s);

@@ -428,9 +428,11 @@ __global__ void __launch_bounds__(64) k_bias_fixup(const E1Job *__restrict__ job
 
 // ---- partition 2: pixels by (px, sign) (512 keys); symbols >= 20 bypass the re-mapper -----
 // k_map_count also brings S2's output back to raster order (gather through pos2).
-__device__ __forceinline__ bool mapper_item(int x, uint32_t ps, uint32_t &key, int &y) {
+// GEN = the job's own near (the serial modes); otherwise the lossless constant, so the divide folds away
+template <bool GEN = false>
+__device__ __forceinline__ bool mapper_item(int x, uint32_t ps, uint32_t &key, int &y, const NearParams &np = NearParams{0, 1, 65537}) {
     int px = int(ps & 0xFF), sign = int(ps >> 8);
-    y = residual_to_symbol(x, px, sign, 0);
+    y = GEN ? residual_to_symbol(x, px, sign, np) : residual_to_symbol(x, px, sign, 0);
     key = uint32_t(px) * 2u + uint32_t(sign);
     return y < kMapSyms;
 }
@@ -485,10 +487,38 @@ __global__ void __launch_bounds__(256) k_map_count(const E1Job *__restrict__ job
     for (int k = lane_id(); k < 512; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
 }
 
+// The same histogram when px | sign was left in raster order by the serial model stage
+// (serial_engine.hip k_serial_model): no gather, the job's own near.
+__global__ void __launch_bounds__(256) k_map_count_pre(const E1Job *__restrict__ jobs) {
+    __shared__ uint32_t lds[4][512];
+    const E1Job &J = jobs[blockIdx.y];
+    const auto x = gptr(J.b.img); const auto pxs = gptr(J.b.pxs); const auto table = gptr(J.b.table);
+    const uint32_t n = J.n; const SegPlan plan = J.pp;
+    const NearParams np = near_params(J.near);
+    int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+    if (seg >= plan.nseg) return;
+    uint32_t *hist = lds[threadIdx.x >> 6];
+    lds_fill<512>(hist, 0);
+    uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
+    for (uint32_t base = lo; base < hi; base += 512) {
+        uint32_t p[8], xx[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const uint32_t t = min(base + 64u * uint32_t(k) + uint32_t(lane_id()), hi - 1); p[k] = pxs[t]; xx[k] = x[t]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t key; int y;
+            if (base + 64u * uint32_t(k) + uint32_t(lane_id()) < hi && mapper_item<true>(int(xx[k]), p[k], key, y, np)) atomicAdd(&hist[key], 1u);
+        }
+    }
+    for (int k = lane_id(); k < 512; k += 64) table[size_t(k) * plan.nseg + seg] = hist[k];
+}
+
 // pos3[t] = position of pixel t in s3in/s3out, or 0x80000000 | y when the symbol bypasses the re-mapper
+template <bool GEN>
 __global__ void __launch_bounds__(256) k_map_scatter(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][512];
     const E1Job &J = jobs[blockIdx.y];
+    const NearParams np = near_params(GEN ? J.near : 0);
     const auto x = gptr(J.b.img); const auto pxs = gptr(J.b.pxs);
     const auto table = gptr(J.b.table); const auto s3in = gptr(J.b.s3in); const auto pos3 = gptr(J.b.pos3);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
@@ -515,7 +545,7 @@ __global__ void __launch_bounds__(256) k_map_scatter(const E1Job *__restrict__ j
             const uint32_t t = gbase + 64u * uint32_t(k) + uint32_t(lane_id());
             uint32_t key = 0; int y = 0;
             const bool in = t < hi;
-            const bool valid = mapper_item(int(cur_x[k]), cur_p[k], key, y) && in;
+            const bool valid = mapper_item<GEN>(int(cur_x[k]), cur_p[k], key, y, np) && in;
             if (in && !valid) pos3[t] = 0x80000000u | uint32_t(y);    // y >= 20 codes as itself (NBLIC.c:488)
             const uint64_t same = match_lanes<9>(key, valid);
             if (valid) {
@@ -589,6 +619,13 @@ __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ 
 }
 
 // ---- S4: binarisation (NBLIC.c:640-679); path depends on (qu,qv,qw,z) only ----------------
+// GEN = the job's k_step (near-lossless modes), divisions from its level_shift_table
+template <bool GEN, class Step>
+__device__ __forceinline__ int walk_job(const E1Job &J, int qu, int qv, int z, Step step) {
+    return GEN ? walk_symbol_t(J.k_step, J.ktab, qu, qv, z, step) : walk_symbol(kMinKStep, qu, qv, z, step);
+}
+
+template <bool GEN>
 __global__ void __launch_bounds__(256) k_count_bins(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
     const auto rec1 = gptr(J.b.rec1); const auto s3out = gptr(J.b.s3out);
@@ -600,10 +637,11 @@ __global__ void __launch_bounds__(256) k_count_bins(const E1Job *__restrict__ jo
     int zz = (p >> 31) ? int(p & 0xFF) : int(s3out[p]);           // back to raster order
     z[t] = uint8_t(zz);
     int c = 0;
-    walk_symbol(kMinKStep, L.qu, L.qv, zz, [&](int, int, int, int bin) { c++; return bin; });
+    walk_job<GEN>(J, L.qu, L.qv, zz, [&](int, int, int, int bin) { c++; return bin; });
     cnt[t] = uint8_t(c);
 }
 
+template <bool GEN>
 __global__ void __launch_bounds__(256) k_emit_bins(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
     const auto rec1 = gptr(J.b.rec1); const auto z = gptr(J.b.z);
@@ -612,7 +650,7 @@ __global__ void __launch_bounds__(256) k_emit_bins(const E1Job *__restrict__ job
     if (t >= J.n) return;
     Level L = s1_level(rec1[t]);
     auto out = events + ev_off[t];
-    walk_symbol(kMinKStep, L.qu, L.qv, int(z[t]), [&](int qu, int qv, int node, int bin) {
+    walk_job<GEN>(J, L.qu, L.qv, int(z[t]), [&](int qu, int qv, int node, int bin) {
         *out++ = pack_event(qu, qv, node, L.qw, bin);
         return bin;
     });
@@ -1292,15 +1330,37 @@ void e1_launch_front(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipSt
     mark(); hipLaunchKernelGGL(k_bias_fixup<NbModel>, dim3(kContexts / 64, n_jobs), dim3(64), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_map_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<1>(d_jobs, n_jobs, 512u * max_nseg, s, mark);
-    mark(); hipLaunchKernelGGL(k_map_scatter, seg_grid, dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_map_scatter<false>, seg_grid, dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_mapper_chains, dim3(512 / kMapLanes, n_jobs), dim3(64), 0, s, d_jobs);
-    mark(); hipLaunchKernelGGL(k_count_bins, px_grid, dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_count_bins<false>, px_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<2>(d_jobs, n_jobs, max_n, s, mark);
     mark();                                                     // start of the host gap (index 20)
 }
 
+// Front half of the serial modes: rec1 and px | sign per pixel come from the serial model stage
+// (k_serial_model, launched by the caller on the same stream before this), so the partition by
+// context and the context chains are skipped; near and k_step come from the job.
+void e1_launch_front_pre(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s) {
+    int max_nseg = 0; uint32_t max_n = 0;
+    for (int k = 0; k < n_jobs; k++) {
+        max_n = h_jobs[k].n > max_n ? h_jobs[k].n : max_n; max_nseg = h_jobs[k].pp.nseg > max_nseg ? h_jobs[k].pp.nseg : max_nseg;
+    }
+    const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs), px_grid(cdiv(max_n, 256), n_jobs);
+    Marker mark{nullptr, s, 0};
+    hipLaunchKernelGGL(k_map_count_pre, seg_grid, dim3(256), 0, s, d_jobs);
+    scan_exclusive<1>(d_jobs, n_jobs, 512u * max_nseg, s, mark);
+    hipLaunchKernelGGL(k_map_scatter<true>, seg_grid, dim3(256), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_mapper_chains, dim3(512 / kMapLanes, n_jobs), dim3(64), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_count_bins<true>, px_grid, dim3(256), 0, s, d_jobs);
+    scan_exclusive<2>(d_jobs, n_jobs, max_n, s, mark);
+}
+
+void e1_launch_init(const E1Job *d_jobs, int n_jobs, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_state, dim3(16, n_jobs), dim3(256), 0, s, d_jobs);
+}
+
 // Back half: needs n_ev / pe filled in the job records and event-sized buffers.  10 launches.
-void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm) {
+void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStream_t s, E1Timers *tm, bool general) {
     int max_nseg = 0; uint32_t max_n = 0, max_ev = 0;
     for (int k = 0; k < n_jobs; k++) {
         max_n = h_jobs[k].n > max_n ? h_jobs[k].n : max_n; max_ev = h_jobs[k].n_ev > max_ev ? h_jobs[k].n_ev : max_ev;
@@ -1308,7 +1368,9 @@ void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
     }
     const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs);
     Marker mark{tm, s, 21};
-    mark(); hipLaunchKernelGGL(k_emit_bins, dim3(cdiv(max_n, 256), n_jobs), dim3(256), 0, s, d_jobs);
+    mark();
+    if (general) hipLaunchKernelGGL(k_emit_bins<true>, dim3(cdiv(max_n, 256), n_jobs), dim3(256), 0, s, d_jobs);
+    else hipLaunchKernelGGL(k_emit_bins<false>, dim3(cdiv(max_n, 256), n_jobs), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_touch_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<3>(d_jobs, n_jobs, 4096u * max_nseg, s, mark);
     mark(); hipLaunchKernelGGL(k_touch_scatter, dim3(seg_grid.x, seg_grid.y, 2), dim3(256), 0, s, d_jobs);

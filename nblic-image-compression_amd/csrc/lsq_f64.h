@@ -19,7 +19,7 @@
 //   is the reference's integer in every case.
 //
 // Shared by the device code (serial_engine.hip) and by the host-side harness of tests/ that
-// checks this arithmetic against the oracle without a GPU.  Compile with -ffp-contract=off.
+// checks this arithmetic against the CPU checker without a GPU.  Compile with -ffp-contract=off.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -39,7 +39,7 @@ constexpr int kDecayS = 3, kDecayV = 5;                 // ALPHA, BETA analogues
 constexpr int kBiasInit = 8, kBiasMax = 4096, kBiasCoef = 21;
 constexpr double kProductLimit = 4611686018427387904.0; // 2^62: beyond it the reference's int64 product may wrap
 constexpr double kEntryLimit = 17592186044416.0;        // 2^44: entries stay exact and the pivot key (|v| * 256 + tag) fits 53 bits
-constexpr double kQuotientLimit = 281474976710656.0;    // 2^48: an estimate this large may be off by more than one
+constexpr double kQuotientLimit = 70368744177664.0;     // 2^46: an estimate this large may be off by more than one
 
 LSQ_HD int order_of(int effort) { return effort == 2 ? 6 : (effort == 3 ? kMaxN : 0); }
 LSQ_HD int vec_len(int n) { return 1 + n + n * n; }     // [s | b(n) | A(n x n)], NBLIC.c:213-215
@@ -50,37 +50,57 @@ struct Guard {
     LSQ_HD bool ok() const { return product < kProductLimit && entry < kEntryLimit && quotient < kQuotientLimit; }
 };
 
-// trunc(n / d) for an integer-valued n with |n| < 2^53, given an estimate rd ~ 1/d.
-// Exact whenever |n / d| < 2^48 (the caller tracks that).
-LSQ_HD double div_trunc(double n, double d, double rd) {
-    const double q0 = trunc(n * rd);
-    const double r = fma(-q0, d, n);                     // exact: |r| < 2|d|
-    const bool nneg = n < 0.0;
-    const double rn = nneg ? -r : r;                     // must end in [0, |d|)
-    const double dir = (nneg != (d < 0.0)) ? -1.0 : 1.0; // sign of the quotient
-    const double adj = rn < 0.0 ? -dir : (rn >= fabs(d) ? dir : 0.0);
-    return q0 + adj;
+// ---- truncating division by estimate + exact remainder -------------------------------------------
+// The estimate is made with a reciprocal that is deliberately SHORT by a factor (1 - 2^-48): then
+// |trunc(estimate)| is never above |trunc(true quotient)| and at most one below it while the quotient
+// is below 2^46, so a single one-sided correction (is the remainder still >= |d| ?) finishes it, and
+// the reciprocal itself needs no more than ~2^-50 relative accuracy (hardware seed + two Newton
+// steps on the device; checked there by nblic_amd_serial_selftest).
+constexpr double kShort = 1.0 - 3.5527136788005009e-15;               // 1 - 2^-48
+
+LSQ_HD double recip_short(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r * kShort;
+#else
+    return (1.0 / d) * kShort;
+#endif
+}
+
+// +-1.0 with the sign of a * b
+LSQ_HD double unit_with_sign_of(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int hi = ((__double2hiint(a) ^ __double2hiint(b)) & int(0x80000000u)) | 0x3FF00000;
+    return __hiloint2double(hi, 0);
+#else
+    return copysign(1.0, a) * copysign(1.0, b);
+#endif
+}
+
+// trunc(n / d) for an integer-valued n with |n| < 2^53; rs = recip_short(d).  Exact while |n / d| < 2^46.
+LSQ_HD double div_trunc(double n, double d, double rs) {
+    const double q0 = trunc(n * rs);
+    const double r = fma(-q0, d, n);                     // exact; same sign as n, |r| < 2|d|
+    return fabs(r) >= fabs(d) ? q0 + unit_with_sign_of(n, d) : q0;
 }
 
 // trunc(a * b / d) with the product carried exactly as p + e (|a b| may exceed 2^53).
-LSQ_HD double muldiv_trunc(double a, double b, double d, double rd, Guard &g) {
+LSQ_HD double muldiv_trunc(double a, double b, double d, double rs, Guard &g) {
     const double p = a * b;
     const double e = fma(a, b, -p);                      // a*b == p + e exactly
-    const double q0 = trunc(p * rd);
+    const double q0 = trunc(p * rs);
     const double r = fma(-q0, d, p) + e;                 // exact remainder of the estimate
-    const bool nneg = p < 0.0;
-    const double rn = nneg ? -r : r;
-    const double dir = (nneg != (d < 0.0)) ? -1.0 : 1.0;
-    const double adj = rn < 0.0 ? -dir : (rn >= fabs(d) ? dir : 0.0);
     g.product = fmax(g.product, fabs(p));
-    return q0 + adj;
+    return fabs(r) >= fabs(d) ? q0 + unit_with_sign_of(p, d) : q0;
 }
 
-// (v * (ab-1) + ab/2) / ab, truncating (NBLIC.c:199, :273-279); |v| < 2^50
+// (v * (ab-1) + ab/2) / ab, truncating (NBLIC.c:199, :273-279); |v| < 2^44
 template <int AB>
 LSQ_HD double decay(double v) {
     const double n = fma(v, double(AB - 1), double(AB / 2));
-    return div_trunc(n, double(AB), 1.0 / double(AB));
+    return div_trunc(n, double(AB), kShort / double(AB));
 }
 LSQ_HD double decay_k(double v, int k) { return k ? decay<kDecayV>(v) : decay<kDecayS>(v); }
 
@@ -92,7 +112,7 @@ LSQ_HD double sample_weight(double s_sum) {
 
 // one entry of the new sample (NBLIC.c:253-267): (prod << shift + s/2) / s with prod = (x-128)*vn_k
 // (shift 28) or vn_j*vn_k (shift 18); |prod| <= 2^14
-LSQ_HD double sample_entry(int prod, double scale, double s, double rs) {
+LSQ_HD double sample_entry(int prod, double scale, double s, double rs) {     // rs = recip_short(s)
     const double n = fma(double(prod), scale, floor(s * 0.5));
     return div_trunc(n, s, rs);
 }
@@ -102,10 +122,10 @@ constexpr double kScaleA = 262144.0;                     // 1 << (4 + FB2 + FB1)
 // contribution of coefficient k to the Q12 prediction (NBLIC.c:233-236): (b*vn*4 + (d >> 1)) / d
 LSQ_HD double term(double b, int vn, double d, Guard &g) {
     const double n = fma(b, double(vn * (1 << kFb2)), floor(d * 0.5));
-    const double rd = 1.0 / d;
-    g.quotient = fmax(g.quotient, fabs(n * rd));
+    const double rs = recip_short(d);
+    g.quotient = fmax(g.quotient, fabs(n * rs));
     g.entry = fmax(g.entry, fabs(b));
-    return div_trunc(n, d, rd);
+    return div_trunc(n, d, rs);
 }
 
 // the two candidate regularisation strengths around `bias` (NBLIC.c:837-842)

@@ -266,6 +266,62 @@ NB_HD int walk_symbol(int k_step, int qu, int qv, int z_in, Step step) {
     return z;
 }
 
+// ---- near-lossless arithmetic without integer divides (the serial kernels run one pixel at a time:
+// a divide by the run-time step 2*near+1 or by k_step would cost ~40 instructions each) ----------
+// floor(num / (2*near+1)) for 0 <= num < 2048 by reciprocal multiply (checked exhaustively in tests/)
+struct NearParams { int near, width, recip; };
+NB_HD NearParams near_params(int near) { return NearParams{near, 2 * near + 1, 65536 / (2 * near + 1) + 1}; }
+NB_HD int div_width(int num, const NearParams &p) { return (num * p.recip) >> 16; }
+NB_HD int residual_to_symbol(int x, int px, int sign, const NearParams &p) {
+    int m = px < kMaxVal - px ? px : kMaxVal - px;
+    int ty = div_width(m + p.near, p);
+    int y = div_width(iabs(x - px) + p.near, p);
+    if (y <= 0) return 0;
+    if (y <= ty) return 2 * y - (int(x >= px) ^ sign);
+    return y + ty;
+}
+NB_HD int symbol_to_pixel(int y, int px, int sign, const NearParams &p) {
+    int m = px < kMaxVal - px ? px : kMaxVal - px;
+    int ty = div_width(m + p.near, p), mag, up;
+    if (y <= 0)           { mag = 0;           up = 0; }
+    else if (y <= 2 * ty) { mag = (y + 1) >> 1; up = (y & 1) ^ sign; }
+    else                  { mag = y - ty;      up = px < kMid; }
+    mag *= p.width;
+    return iclip(up ? px + mag : px - mag, 0, kMaxVal);
+}
+
+// level / k_step for the sixteen levels, four bits each (bits 60..63 = 15 / k_step = k_max)
+NB_HD uint64_t level_shift_table(int k_step) {
+    uint64_t t = 0;
+    for (int q = 0; q < kLevels; q++) t |= uint64_t(q / k_step) << (4 * q);
+    return t;
+}
+// walk_symbol with the divisions looked up in level_shift_table(k_step)
+template <class Step>
+NB_HD int walk_symbol_t(int k_step, uint64_t ktab, int qu, int qv, int z_in, Step step) {
+    const int k_max = int(ktab >> 60);
+    const bool decoding = z_in < 0;
+    int node = 0, bin, z;
+    int k = int(ktab >> (4 * qu)) & 15;
+    if ((int(ktab >> (4 * qv)) & 15) != k) qv = qu;
+    for (;;) {
+        bin = decoding ? -1 : int((node >> k_max) < (z_in >> k));
+        bin = step(qu, qv, node, bin);
+        if (!bin) break;
+        node += 1 << k_max;
+        if (node >= kTreeNodes) { node >>= 1; k++; qu = qv = k * k_step; }
+    }
+    z = decoding ? ((node >> k_max) << k) : z_in;
+    node++;
+    for (k--; k >= 0; k--) {
+        bin = decoding ? -1 : ((z_in >> k) & 1);
+        bin = step(qu, qv, node, bin);
+        if (decoding && bin) z += 1 << k;
+        node += bin ? (1 << k) : 1;
+    }
+    return z;
+}
+
 // ---- record packing shared by the staged -e1 kernels -------------------------------------
 // S1 record, one u32 per pixel:  px0[0:8) | adr[8:19) | qw[19:24) | qu_lsb[24] | qv_rel[25:27)
 // qv_rel: 0 -> qv == qu, 1 -> qv == qu + 1, 2 -> qv == qu - 1.  qu = ((adr >> 8) << 1) | qu_lsb.

@@ -1,11 +1,13 @@
 // pipeline.hip -- host side of libnblic_amd.so: workspaces, streams, the serial range-coder
 // stage (S6) on host threads, and the C ABI declared in include/nblic_amd.h.
 //
-// One `Slot` = one image in flight on the GPU: its own HIP stream, device workspace and a
-// pinned host buffer that receives the coded-bin stream (u16 per bin).  The submission thread
-// keeps every free slot busy; as soon as a slot's device->host copy lands, a coder thread
-// turns the bins into the byte-exact range-coder stream (NBLIC.c:552-586) while the GPU is
-// already working on the next images.
+// Images in flight are split into GROUPS that share every kernel launch (a driver thread and a HIP
+// stream per group).  A finished image's coded bins (u16 per bin) stay in an HBM buffer of a pool
+// until a coder thread streams them to the host chunk by chunk through its own small pinned ring
+// and turns them into the byte-exact range-coder stream (NBLIC.c:552-586), while the GPU is already
+// working on the next groups.  Three kinds of group: staged -n0 -e1 encode, QNBLIC (effort 0) encode,
+// and the serial modes (near > 0, efforts 2/3), whose front half is the one-wave-per-image model
+// stage of serial_engine.hip and whose entropy stages are the same parallel kernels.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -150,8 +152,9 @@ struct ReadyImage {                                                  // everythi
     int cb, job, h, w;
     uint32_t n_ev;
     unsigned char *const *outs; const size_t *caps; long *lens;      // -e1: byte streams; effort 0: uint16_t streams, caps/lens in words
-    int kind;                                                        // 0 = NBLIC -e1 range coder, 1 = QNBLIC entropy stage
+    int kind;                                                        // 0 / 2 = NBLIC range coder, 1 = QNBLIC entropy stage
     ::nblic_amd_batch *batch;                                        // whose completion this image counts towards
+    int near, k_step, effort;                                        // header fields (NBLIC.c:682-694)
 };
 
 // ---- one image in flight -------------------------------------------------------------------
@@ -161,7 +164,11 @@ struct Slot {
     uint8_t *d_img = nullptr;         // device copy when the caller hands a host image
     int cb = -1;                      // coded-bin buffer (HBM) this image's back half writes to
     int job = -1, h = 0, w = 0;       // current image
+    int near = 0, effort = 1;         // its mode (kind 2 groups; 0 / 1 otherwise)
     uint32_t n_ev = 0;
+    // serial modes: reconstruction (near > 0) and least-squares statistics (efforts 2/3)
+    uint8_t *d_recon = nullptr; size_t recon_cap = 0;
+    double *d_stats = nullptr; size_t stats_cap = 0;
 };
 
 // ---- a group of images that shares every kernel launch ---------------------------------------
@@ -172,6 +179,8 @@ struct Group {
     E1Timers tm{};
     std::vector<Slot> slots;
     E1Job *h_jobs = nullptr, *d_jobs = nullptr;        // pinned host / device job records
+    SerialJob *h_sjobs = nullptr, *d_sjobs = nullptr;  // the same images for the serial model stage (kind 2)
+    unsigned char *const *recons = nullptr;            // kind 2: where each image's reconstruction goes (host; entries may be null)
     uint32_t *h_totals = nullptr, *d_totals = nullptr; // 4 words per slot
     int n_jobs = 0;
     bool tm_pending = false;                           // timer events recorded, not yet read
@@ -237,7 +246,10 @@ struct nblic_amd_ctx {
     double wait_s = 0;                    // of coder_s: waiting for bins to arrive from HBM
     long takes[kMaxTake + 1] = {0};       // how many times a thread took k images together
     std::mutex stat_m;
-    SerialEngine serial;
+    // decode batches (nblic_amd_decode_batch): a stream of their own and grow-only device / pinned arenas
+    hipStream_t dec_stream = nullptr;
+    uint8_t *dec_arena = nullptr; size_t dec_arena_cap = 0;
+    SerialJob *dec_jobs = nullptr; int *dec_status = nullptr; int dec_jobs_cap = 0;
 };
 
 namespace nblic {
@@ -250,6 +262,8 @@ static bool group_init(Group &g, int id, int n_slots, nblic_amd_ctx *c) {
     for (auto &e : g.tm.ev) HIP_OK(hipEventCreate(&e));
     HIP_OK(hipHostMalloc((void **)&g.h_jobs, size_t(n_slots) * sizeof(E1Job), hipHostMallocDefault));
     HIP_OK(hipMalloc((void **)&g.d_jobs, size_t(n_slots) * sizeof(E1Job)));
+    HIP_OK(hipHostMalloc((void **)&g.h_sjobs, size_t(n_slots) * sizeof(SerialJob), hipHostMallocDefault));
+    HIP_OK(hipMalloc((void **)&g.d_sjobs, size_t(n_slots) * sizeof(SerialJob)));
     HIP_OK(hipHostMalloc((void **)&g.h_totals, size_t(n_slots) * 4 * sizeof(uint32_t), hipHostMallocDefault));
     HIP_OK(hipMalloc((void **)&g.d_totals, size_t(n_slots) * 4 * sizeof(uint32_t)));
     for (int k = 0; k < n_slots; k++) {
@@ -275,8 +289,10 @@ static void group_free(Group &g) {
         hipFree(s.b.pos3); hipFree(s.b.s3out); hipFree(s.b.z); hipFree(s.b.cnt); hipFree(s.b.ev_off); hipFree(s.b.table);
         hipFree(s.b.scan_sums); hipFree(s.b.ctx_state); hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events);
         hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.dbg_out); hipFree(s.b.qhist); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
+        hipFree(s.d_recon); hipFree(s.d_stats);
     }
-    hipFree(g.d_jobs); hipFree(g.d_totals);
+    hipFree(g.d_jobs); hipFree(g.d_totals); hipFree(g.d_sjobs);
+    if (g.h_sjobs) hipHostFree(g.h_sjobs);
     if (g.h_jobs) hipHostFree(g.h_jobs);
     if (g.h_totals) hipHostFree(g.h_totals);
     for (auto &e : g.tm.ev) if (e) hipEventDestroy(e);
@@ -326,6 +342,59 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
     e1_launch_front(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);
+    HIP_OK(hipMemcpyAsync(g.h_totals, g.d_totals, size_t(g.n_jobs) * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    return true;
+}
+
+// Front half of a serial-mode group (near > 0 and / or efforts 2, 3): model state init, the serial
+// model stage (one wave per image, all images of the group side by side; the slots are ordered by
+// effort, one launch per effort present), the reconstructions on their way back to the host, then
+// the re-mapper partition and chains and the bin counts.
+static bool launch_front_serial(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, bool on_device) {
+    for (int k = 0; k < g.n_jobs; k++) {
+        Slot &s = g.slots[size_t(k)];
+        const size_t n = size_t(s.h) * size_t(s.w);
+        if (!ensure_pixels(s, n)) return false;
+        if (on_device) {
+            s.b.img = imgs[s.job];
+        } else {
+            if (n > s.img_cap) { if (!dev_alloc(s.d_img, n)) return false; s.img_cap = n; }
+            HIP_OK(hipMemcpyAsync(s.d_img, imgs[s.job], n, hipMemcpyHostToDevice, g.stream));
+            s.b.img = s.d_img;
+        }
+        const bool wide = 3 * ((s.w + 15) & ~15) > 140 * 1024;          // rows do not fit in LDS: taps come from the reconstruction in memory
+        const bool want_recon = s.near > 0 || wide;
+        if (want_recon && n > s.recon_cap) { if (!dev_alloc(s.d_recon, n)) return false; s.recon_cap = n; }
+        const size_t st = stats_doubles(s.effort, s.w);
+        if (st > s.stats_cap) { if (!dev_alloc(s.d_stats, st)) return false; s.stats_cap = st; }
+        if (st) HIP_OK(hipMemsetAsync(s.d_stats, 0, st * sizeof(double), g.stream));         // NBLIC.c:789
+        E1Job &J = g.h_jobs[k];
+        J.b = s.b; J.h = s.h; J.w = s.w; J.n = uint32_t(n); J.pp = make_plan(J.n); J.n_ev = 0; J.pe = make_plan(0, kTouchSegments); J.dbg = 0;
+        J.near = s.near; J.k_step = k_step_for_near(s.near); J.ktab = level_shift_table(J.k_step);
+        SerialJob &Q = g.h_sjobs[k];
+        Q = SerialJob{};
+        Q.img = s.b.img; Q.recon = want_recon ? s.d_recon : nullptr; Q.rec1 = s.b.rec1; Q.pxs = s.b.pxs; Q.stats = s.d_stats;
+        Q.h = s.h; Q.w = s.w; Q.near = s.near; Q.k_step = J.k_step; Q.effort = s.effort;
+    }
+    HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
+    HIP_OK(hipMemcpyAsync(g.d_sjobs, g.h_sjobs, size_t(g.n_jobs) * sizeof(SerialJob), hipMemcpyHostToDevice, g.stream));
+    e1_launch_init(g.d_jobs, g.n_jobs, g.stream);
+    for (int k0 = 0; k0 < g.n_jobs;) {
+        int k1 = k0 + 1;
+        while (k1 < g.n_jobs && g.slots[size_t(k1)].effort == g.slots[size_t(k0)].effort) k1++;
+        if (!serial_model_launch(g.d_sjobs + k0, g.h_sjobs + k0, k1 - k0, g.stream)) return false;
+        k0 = k1;
+    }
+    for (int k = 0; k < g.n_jobs; k++) {                                 // the encoder leaves the reconstruction in the caller's plane (NBLIC.c:876)
+        Slot &s = g.slots[size_t(k)];
+        unsigned char *dst = g.recons ? g.recons[s.job] : nullptr;
+        if (!dst) continue;
+        const size_t n = size_t(s.h) * size_t(s.w);
+        if (s.near > 0) HIP_OK(hipMemcpyAsync(dst, s.d_recon, n, hipMemcpyDeviceToHost, g.stream));
+        else if (!on_device && dst != imgs[s.job]) memcpy(dst, imgs[s.job], n);
+        else if (on_device) HIP_OK(hipMemcpyAsync(dst, imgs[s.job], n, hipMemcpyDeviceToHost, g.stream));
+    }
+    e1_launch_front_pre(g.d_jobs, g.h_jobs, g.n_jobs, g.stream);
     HIP_OK(hipMemcpyAsync(g.h_totals, g.d_totals, size_t(g.n_jobs) * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
     return true;
 }
@@ -453,7 +522,7 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
 static int coder_take(const nblic_amd_ctx *c) {                  // call with c->rm held; 0 = nothing to take
     const size_t q = c->ready.size();
     if (q == 0) return 0;
-    if (c->ready.front().kind != 0 || !c->simd) return 1;
+    if (c->ready.front().kind == 1 || !c->simd) return 1;
     const size_t left = q + size_t(c->batch_to_come), threads = c->coders.size();
     if (left <= 2 * threads) return 1;                           // two rounds of singles beat one small pack
     if (q < size_t(kMaxTake) && c->batch_to_come > 0 && left >= 4 * threads && c->idle_coders <= 1) return 0;   // mid-batch, every other thread busy: wait (~30 ms) for a full pack
@@ -475,7 +544,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
             if (take == 0) break;                                // shutdown while waiting for a pack to fill
             c->idle_coders--;
             for (int k = 0; k < take; k++) {
-                if (k > 0 && c->ready.front().kind != 0) { take = k; break; }
+                if (k > 0 && c->ready.front().kind == 1) { take = k; break; }
                 im[k] = c->ready.front(); c->ready.pop_front();
             }
         }
@@ -513,7 +582,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
             const size_t cap = im[k].caps[im[k].job] < (size_t(1) << 46) ? im[k].caps[im[k].job] : (size_t(1) << 46);   // SIZE_MAX = "no limit"
             dst[k] = im[k].outs[im[k].job] + kHeaderBytes;
             caps[k] = cap >= size_t(kHeaderBytes) ? cap - kHeaderBytes : 0;
-            if (cap >= size_t(kHeaderBytes)) write_header(im[k].outs[im[k].job], im[k].h, im[k].w, 0, kMinKStep, 1);
+            if (cap >= size_t(kHeaderBytes)) write_header(im[k].outs[im[k].job], im[k].h, im[k].w, im[k].near, im[k].k_step, im[k].effort);
         }
         static const bool skip_coding = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 16);   // measurement aid: device side alone
         if (skip_coding) { for (int k = 0; k < take; k++) lens[k] = 0; }
@@ -568,7 +637,7 @@ static void on_group_done(void *vp) {
         std::lock_guard<std::mutex> l(c->rm);
         for (int k = 0; k < gp->n_jobs; k++) {
             const Slot &s = gp->slots[size_t(k)];
-            c->ready.push_back(ReadyImage{s.cb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens, gp->kind, gp->batch});
+            c->ready.push_back(ReadyImage{s.cb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens, gp->kind, gp->batch, s.near, k_step_for_near(s.near), s.effort});
         }
         c->batch_to_come -= gp->n_jobs;
     }
@@ -577,7 +646,7 @@ static void on_group_done(void *vp) {
     c->fcv.notify_all();
 }
 
-static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders) {
+static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders, bool general = false) {
     // a BLOCKING wait: a spinning one per driver thread would take cores from the coder threads
     HIP_OK(hipEventRecord(g.done, g.stream));
     HIP_OK(hipEventSynchronize(g.done));
@@ -593,8 +662,8 @@ static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders) {
         J.b = s.b; J.n_ev = s.n_ev; J.pe = make_plan(s.n_ev, kTouchSegments);
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
-    e1_launch_back(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);
-    g.tm_pending = c->timing;
+    e1_launch_back(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, (c->timing && !general) ? &g.tm : nullptr, general);
+    g.tm_pending = c->timing && !general;
     if (with_coders) HIP_OK(hipLaunchHostFunc(g.stream, on_group_done, &g));       // the caller has counted the images in ctx->coding
     return true;
 }
@@ -628,6 +697,7 @@ static void driver_main(nblic_amd_ctx *c, int id) {
             g.has_work = false;
         }
         const bool ok = g.kind == 0 ? (launch_front(c, g, g.imgs, g.on_device) && launch_back(c, g, true))
+                      : g.kind == 2 ? (launch_front_serial(c, g, g.imgs, g.on_device) && launch_back(c, g, true, true))
                                     : launch_q(c, g, g.imgs, g.on_device);
         if (!ok) {
             c->failed = true;
@@ -662,7 +732,8 @@ static void start_group(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, 
 // groups still in flight finish on their own; encode_wait() collects.  Several batches may be
 // outstanding: the next one fills the pipeline while this one drains.
 static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, const uint8_t *const *imgs, bool on_device,
-                          const int *hs, const int *ws, uint8_t *const *outs, const size_t *caps, long *lens) {
+                          const int *hs, const int *ws, uint8_t *const *outs, const size_t *caps, long *lens,
+                          const int *nears = nullptr, const int *efforts = nullptr, unsigned char *const *recons = nullptr) {
     bool idle;
     { std::lock_guard<std::mutex> l(c->fm); idle = c->coding == 0; }
     if (idle) {                                                   // nothing outstanding: start the reporting afresh
@@ -675,9 +746,23 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
     }
     b->n_images = n_images; b->lens = lens;
     for (int k = 0; k < n_images; k++) lens[k] = -1;
-    { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come += n_images; }
-    int next = 0;
-    while (next < n_images) {
+    // modes: (near, effort) clamped as the reference clamps them (NBLIC.c:768-770); -n0 -e1 images take the
+    // staged pipeline (kind 0), everything else the serial model stage (kind 2).  Images are handed out kind by
+    // kind and, inside kind 2, effort by effort, so a group's launches are homogeneous.
+    auto near_of = [&](int k) { return nears ? iclip(nears[k], 0, kMaxNear) : 0; };
+    auto effort_of = [&](int k) { return efforts ? iclip(efforts[k], 1, 3) : 1; };
+    auto class_of = [&](int k) { return (near_of(k) == 0 && effort_of(k) == 1) ? 0 : effort_of(k); };   // 0 staged; 1..3 serial by effort
+    std::vector<int> order;
+    order.reserve(size_t(n_images));
+    for (int cls = 0; cls <= 3; cls++)
+        for (int k = 0; k < n_images; k++) {
+            if (class_of(k) != cls) continue;
+            if (!size_ok(hs[k], ws[k], c->max_px)) { b->ok = false; continue; }
+            order.push_back(k);
+        }
+    { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come += int(order.size()); }
+    size_t next = 0;
+    while (next < order.size()) {
         int id;
         {
             std::unique_lock<std::mutex> l(c->fm);
@@ -686,15 +771,19 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
         }
         Group &g = c->groups[size_t(id)];
         collect_timing(c, g);                               // events of its previous use are complete by now
-        g.outs = outs; g.caps = caps; g.lens = lens; g.kind = 0; g.batch = b;
+        const int kind = class_of(order[next]) == 0 ? 0 : 2;
+        g.outs = outs; g.caps = caps; g.lens = lens; g.kind = kind; g.batch = b; g.recons = recons;
         g.n_jobs = 0;
-        while (next < n_images && g.n_jobs < int(g.slots.size())) {
-            int k = next++;
-            if (!size_ok(hs[k], ws[k], c->max_px)) { b->ok = false; std::lock_guard<std::mutex> l(c->rm); c->batch_to_come--; continue; }
+        while (next < order.size() && g.n_jobs < int(g.slots.size()) && (class_of(order[next]) == 0 ? 0 : 2) == kind) {
+            const int k = order[next++];
             Slot &s = g.slots[size_t(g.n_jobs++)];
-            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1;
+            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1; s.near = near_of(k); s.effort = effort_of(k);
+            if (kind == 0 && recons && recons[k]) {                       // -n0 -e1: the reconstruction IS the input (NBLIC.c:876 rewrites the same bytes)
+                const size_t n = size_t(hs[k]) * size_t(ws[k]);
+                if (on_device) { if (hipMemcpy(recons[k], imgs[k], n, hipMemcpyDeviceToHost) != hipSuccess) b->ok = false; }
+                else if (recons[k] != imgs[k]) memcpy(recons[k], imgs[k], n);
+            }
         }
-        if (g.n_jobs == 0) { release_group(c, id); continue; }
         start_group(c, g, imgs, on_device);
     }
 }
@@ -789,7 +878,7 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
             int k = next++;
             if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; std::lock_guard<std::mutex> l(c->rm); c->batch_to_come--; continue; }
             Slot &s = g.slots[size_t(g.n_jobs++)];
-            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1;
+            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1; s.near = 0; s.effort = 1;
         }
         if (g.n_jobs == 0) { release_group(c, id); continue; }
         start_group(c, g, imgs, on_device);
@@ -800,6 +889,118 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
     }
     for (int k = 0; k < n_images; k++) if (len_words[k] < 0) ok = false;
     return ok && !c->failed;
+}
+
+// ---- decoders: every stream of a batch side by side, one wave per image (serial_engine.hip) -----
+long q_decode_tables(const uint16_t *in, size_t n_words, int *h, int *w, uint32_t *freq, uint32_t *start, uint8_t *slot);
+
+struct DecodeItem { int k, h, w, near, k_step, effort, kind; size_t len; };      // kind 0 NBLIC, 1 QNBLIC
+
+// Parses and validates the headers (NBLIC.c:698-745, QNBLIC.c:475-486), uploads the streams, launches one
+// kernel per (codec, effort) class present and copies the planes back.  status[k] = 0 / -1 per image.
+static bool decode_batch(nblic_amd_ctx *c, int n, const unsigned char *const *streams, const size_t *lens,
+                         unsigned char *const *imgs, const size_t *img_caps, int *hs, int *ws, int *nears, int *efforts, int *status) {
+    if (hipSetDevice(c->device) != hipSuccess) return false;
+    constexpr size_t kQTab = 2 * 12 * 256 * sizeof(uint32_t) + size_t(12) * 32768;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    std::vector<DecodeItem> items;
+    size_t arena = 0;
+    for (int k = 0; k < n; k++) {
+        status[k] = -1; hs[k] = ws[k] = 0; nears[k] = efforts[k] = 0;
+        const unsigned char *p = streams[k];
+        DecodeItem it{k, 0, 0, 0, 0, 0, 0, lens[k]};
+        if (lens[k] >= kHeaderBytes + 4 && memcmp(p, "NBLIC0.3", 8) == 0) {
+            const int n_channel = p[8];
+            it.h = (p[9] << 8) | p[10]; it.w = (p[11] << 8) | p[12]; it.near = p[13]; it.k_step = p[14]; it.effort = p[15];
+            if (!size_ok(it.h, it.w, c->max_px) || n_channel > 1 || it.near > kMaxNear || it.k_step < kMinKStep || it.k_step > kLevels ||
+                it.effort < 1 || it.effort > 3) continue;
+        } else if (lens[k] >= 12 && p[0] == 'Q' && p[1] == '0' && p[2] == '.' && p[3] == '2') {
+            const uint16_t *q = reinterpret_cast<const uint16_t *>(p);
+            it.kind = 1; it.h = q[2]; it.w = q[3];
+            if (!size_ok(it.h, it.w, c->max_px)) continue;
+        } else continue;
+        hs[k] = it.h; ws[k] = it.w; nears[k] = it.near; efforts[k] = it.effort;
+        if (size_t(it.h) * size_t(it.w) > img_caps[k]) continue;
+        items.push_back(it);
+        arena += up(lens[k] + 2048) + up(size_t(it.h) * size_t(it.w)) + up(stats_doubles(it.effort, it.w) * sizeof(double)) + (it.kind ? up(kQTab) : 0);
+    }
+    if (items.empty()) return true;
+    std::stable_sort(items.begin(), items.end(), [](const DecodeItem &a, const DecodeItem &b) { return a.kind * 4 + a.effort < b.kind * 4 + b.effort; });
+    const int m = int(items.size());
+    if (arena > c->dec_arena_cap) { hipFree(c->dec_arena); c->dec_arena = nullptr; c->dec_arena_cap = 0; HIP_OK(hipMalloc((void **)&c->dec_arena, arena)); c->dec_arena_cap = arena; }
+    if (m > c->dec_jobs_cap) {
+        hipFree(c->dec_jobs); hipFree(c->dec_status); c->dec_jobs = nullptr; c->dec_status = nullptr; c->dec_jobs_cap = 0;
+        HIP_OK(hipMalloc((void **)&c->dec_jobs, size_t(m) * sizeof(SerialJob)));
+        HIP_OK(hipMalloc((void **)&c->dec_status, size_t(m) * sizeof(int)));
+        c->dec_jobs_cap = m;
+    }
+    hipStream_t st = c->dec_stream;
+    std::vector<SerialJob> jobs(static_cast<size_t>(m));
+    std::vector<uint8_t> qtab;
+    size_t off = 0;
+    for (int i = 0; i < m; i++) {
+        const DecodeItem &it = items[size_t(i)];
+        SerialJob &J = jobs[size_t(i)];
+        J = SerialJob{};
+        uint8_t *d_stream = c->dec_arena + off; off += up(it.len + 2048);
+        J.recon = c->dec_arena + off; off += up(size_t(it.h) * size_t(it.w));
+        const size_t sb = stats_doubles(it.effort, it.w) * sizeof(double);
+        if (sb) { J.stats = reinterpret_cast<double *>(c->dec_arena + off); off += up(sb); HIP_OK(hipMemsetAsync(J.stats, 0, sb, st)); }
+        HIP_OK(hipMemsetAsync(d_stream + (it.len & ~size_t(3)), 0, 2048, st));                 // the window reads whole 512-byte blocks past the end
+        HIP_OK(hipMemcpyAsync(d_stream, streams[it.k], it.len, hipMemcpyHostToDevice, st));
+        J.stream = d_stream; J.stream_len = it.len; J.status = c->dec_status + i;
+        J.h = it.h; J.w = it.w; J.near = it.near; J.k_step = it.k_step; J.effort = it.effort;
+        if (it.kind == 1) {                                              // QNBLIC: histogram tables parsed on the host
+            qtab.resize(kQTab);
+            uint32_t *freq = reinterpret_cast<uint32_t *>(qtab.data()), *start = freq + 12 * 256;
+            uint8_t *slot = qtab.data() + 2 * 12 * 256 * sizeof(uint32_t);
+            int hh = 0, ww = 0;
+            const long pos = q_decode_tables(reinterpret_cast<const uint16_t *>(streams[it.k]), it.len / 2, &hh, &ww, freq, start, slot);
+            uint8_t *d_tab = c->dec_arena + off; off += up(kQTab);
+            J.q_pos = pos < 0 ? it.len : size_t(pos); J.q_words = pos < 0 ? 0 : it.len / 2;            // a bad table makes the kernel report failure
+            HIP_OK(hipMemcpy(d_tab, qtab.data(), kQTab, hipMemcpyHostToDevice));                     // synchronous: qtab is reused by the next image
+            J.q_freq = reinterpret_cast<const uint32_t *>(d_tab); J.q_start = J.q_freq + 12 * 256; J.q_slot = d_tab + 2 * 12 * 256 * sizeof(uint32_t);
+        }
+    }
+    HIP_OK(hipMemcpyAsync(c->dec_jobs, jobs.data(), size_t(m) * sizeof(SerialJob), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(c->dec_status, 0xFF, size_t(m) * sizeof(int), st));
+    for (int i0 = 0; i0 < m;) {
+        int i1 = i0 + 1;
+        while (i1 < m && items[size_t(i1)].kind == items[size_t(i0)].kind && items[size_t(i1)].effort == items[size_t(i0)].effort) i1++;
+        const bool ok = items[size_t(i0)].kind == 1 ? serial_qdecode_launch(c->dec_jobs + i0, i1 - i0, st)
+                                                    : serial_decode_launch(c->dec_jobs + i0, jobs.data() + i0, i1 - i0, st);
+        if (!ok) { fprintf(stderr, "[nblic_amd] decode launch failed\n"); hipStreamSynchronize(st); return false; }
+        i0 = i1;
+    }
+    std::vector<int> st_host(static_cast<size_t>(m), -1);
+    HIP_OK(hipMemcpyAsync(st_host.data(), c->dec_status, size_t(m) * sizeof(int), hipMemcpyDeviceToHost, st));
+    for (int i = 0; i < m; i++) {
+        const DecodeItem &it = items[size_t(i)];
+        HIP_OK(hipMemcpyAsync(imgs[it.k], jobs[size_t(i)].recon, size_t(it.h) * size_t(it.w), hipMemcpyDeviceToHost, st));
+    }
+    HIP_OK(hipStreamSynchronize(st));
+    for (int i = 0; i < m; i++) status[items[size_t(i)].k] = st_host[size_t(i)] == 0 ? 0 : -1;
+    return true;
+}
+
+// How many bytes of the caller's stream may be read.  The reference's decoders take no length (NBLIC.h:72,
+// QNBLIC.h:16): they simply read what the encoder wrote.  The drop-in shims bound their copy by the end of
+// the readable mapping that holds `p` and by the worst case a stream of this geometry can have.
+static size_t readable_span(const unsigned char *p, size_t want) {
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f) return want;
+    unsigned long lo, hi, addr = (unsigned long)p, end = 0;
+    char perms[8], line[512];
+    while (fgets(line, sizeof line, f)) {
+        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perms) != 3 || perms[0] != 'r') { if (end) break; continue; }
+        if (!end) { if (addr >= lo && addr < hi) end = hi; }
+        else if (lo == end) end = hi;                                   // contiguous readable mapping
+        else break;
+    }
+    fclose(f);
+    if (!end) return want;
+    const size_t avail = size_t(end - addr);
+    return avail < want ? avail : want;
 }
 
 // ---- default context behind the drop-in entry points ---------------------------------------
@@ -895,7 +1096,7 @@ void nblic_amd_syn1(unsigned char *img, int h, int w, uint32_t seed) {
         }
 }
 
-const char *nblic_amd_version(void) { return "nblic_amd 0.1 (NBLIC v0.3 bitstream, gfx950)"; }
+const char *nblic_amd_version(void) { return "nblic_amd 0.2 (NBLIC v0.3 bitstream, gfx950)"; }
 
 nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int n_coders, int n_host_buffers) {
     int count = 0;
@@ -921,7 +1122,7 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     }
     c->cbufs.resize(size_t(n_host_buffers));
     for (int i = 0; i < n_host_buffers; i++) c->free_cbufs.push_back(i);
-    if (!c->serial.init()) { nblic_amd_destroy(c); return nullptr; }
+    if (hipStreamCreateWithFlags(&c->dec_stream, hipStreamNonBlocking) != hipSuccess) { c->dec_stream = nullptr; nblic_amd_destroy(c); return nullptr; }
     // (Measured and rejected: creating the copy streams with the highest stream priority, so that the
     // coder threads' short interleave kernels and copies overtake the encoder's long kernels -- the
     // pipeline drops from 4.9 to 3.1 Gpx/s.)
@@ -957,11 +1158,15 @@ void nblic_amd_destroy(nblic_amd_ctx *c) {
     for (auto &g : c->groups) group_free(g);
     for (auto &cb : c->cbufs) if (cb.p) hipFree(cb.p);
     for (auto &cs : c->copy_streams) if (cs) hipStreamDestroy(cs);
-    c->serial.destroy();
+    hipFree(c->dec_arena); hipFree(c->dec_jobs); hipFree(c->dec_status);
+    if (c->dec_stream) hipStreamDestroy(c->dec_stream);
     delete c;
 }
 
-void nblic_amd_set_max_pixels(nblic_amd_ctx *c, long max_pixels) { c->max_px = max_pixels > 0 ? max_pixels : kMaxPixels; }
+void nblic_amd_set_max_pixels(nblic_amd_ctx *c, long max_pixels) {
+    if (!c) c = default_ctx();                                               // NULL: the context behind the drop-in entry points
+    if (c) c->max_px = max_pixels > 0 ? max_pixels : kMaxPixels;
+}
 void nblic_amd_enable_timing(nblic_amd_ctx *c, int on) { c->timing = on != 0; }
 
 int nblic_amd_stage_times(nblic_amd_ctx *c, double *ms, const char **names, int cap) {
@@ -1010,7 +1215,7 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
     { std::unique_lock<std::mutex> l(c->fm); c->fcv.wait(l, [c] { return !c->free_groups.empty(); }); id = c->free_groups.front(); c->free_groups.pop_front(); }
     Group &grp = c->groups[size_t(id)];
     Slot &s = grp.slots[0];
-    grp.n_jobs = 1; s.job = 0; s.h = h; s.w = w; s.cb = -1;
+    grp.n_jobs = 1; s.job = 0; s.h = h; s.w = w; s.cb = -1; s.near = 0; s.effort = 1;
     const uint8_t *imgs[1] = {img};
     long count = -1;
     size_t n = size_t(h) * size_t(w);
@@ -1034,6 +1239,31 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
     return count;
 }
 
+int nblic_amd_encode_batch_modes(nblic_amd_ctx *c, int n_images, const unsigned char *const *imgs, int imgs_on_device,
+                                 const int *heights, const int *widths, const int *nears, const int *efforts,
+                                 unsigned char *const *outs, const size_t *out_caps, long *out_lens, unsigned char *const *recons) {
+    if (!c || n_images < 0 || hipSetDevice(c->device) != hipSuccess) return -1;
+    nblic_amd_batch b;
+    { std::lock_guard<std::mutex> g(c->api); encode_submit(c, &b, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps, out_lens, nears, efforts, recons); }
+    const bool ok = encode_wait(c, &b);
+    return ok && !c->failed ? 0 : -1;
+}
+
+int nblic_amd_decode_batch(nblic_amd_ctx *c, int n_images, const unsigned char *const *streams, const size_t *stream_lens,
+                           unsigned char *const *imgs, const size_t *img_caps, int *heights, int *widths, int *nears, int *efforts,
+                           int *status) {
+    if (!c || n_images < 0) return -1;
+    std::lock_guard<std::mutex> g(c->api);
+    if (!decode_batch(c, n_images, streams, stream_lens, imgs, img_caps, heights, widths, nears, efforts, status)) return -1;
+    for (int k = 0; k < n_images; k++) if (status[k] != 0) return -1;
+    return 0;
+}
+
+int nblic_amd_serial_selftest(nblic_amd_ctx *c) {
+    if (!c || hipSetDevice(c->device) != hipSuccess) return -1;
+    return serial_selftest(c->dec_stream);
+}
+
 // ---- drop-in entry points --------------------------------------------------------------------
 int NBLICcompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int height, int width, int *p_near, int *p_effort) {
     (void)verbose;
@@ -1041,36 +1271,28 @@ int NBLICcompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int h
     *p_effort = iclip(*p_effort, 1, 3);                                      // NBLIC.c:770
     int k_step = k_step_for_near(*p_near);
     write_header(p_buf, height, width, *p_near, k_step, *p_effort);          // the reference writes it before validating
-    if (!size_ok(height, width, kMaxPixels)) return -1;
     nblic_amd_ctx *c = default_ctx();
     if (!c) return -1;
-    if (*p_near == 0 && *p_effort == 1) {
-        const unsigned char *imgs[1] = {p_img};
-        unsigned char *outs[1] = {p_buf};
-        size_t caps[1] = {SIZE_MAX};
-        long lens[1] = {-1};
-        if (nblic_amd_encode_batch(c, 1, imgs, 0, &height, &width, outs, caps, lens) != 0) return -1;
-        return int(lens[0]);
-    }
-    std::lock_guard<std::mutex> g(c->api);
-    return int(c->serial.encode(p_buf, p_img, height, width, *p_near, k_step, *p_effort, c->device));
+    if (!size_ok(height, width, c->max_px)) return -1;                       // NBLIC.h:31 unless nblic_amd_set_max_pixels(NULL, ...) raised it
+    const unsigned char *imgs[1] = {p_img};
+    unsigned char *outs[1] = {p_buf}, *recons[1] = {p_img};
+    size_t caps[1] = {SIZE_MAX};
+    long lens[1] = {-1};
+    if (nblic_amd_encode_batch_modes(c, 1, imgs, 0, &height, &width, p_near, p_effort, outs, caps, lens, recons) != 0) return -1;
+    return int(lens[0]);
 }
 
 int NBLICdecompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int *p_height, int *p_width, int *p_near, int *p_effort) {
     (void)verbose;
     if (memcmp(p_buf, "NBLIC0.3", 8) != 0) return -1;                        // NBLIC.c:698-712
-    int n_channel = p_buf[8];
-    *p_height = (p_buf[9] << 8) | p_buf[10];
-    *p_width = (p_buf[11] << 8) | p_buf[12];
-    *p_near = p_buf[13];
-    int k_step = p_buf[14];
-    *p_effort = p_buf[15];
-    if (!size_ok(*p_height, *p_width, kMaxPixels) || n_channel > 1 || *p_near > kMaxNear || k_step < kMinKStep ||
-        k_step > kLevels || *p_effort < 1 || *p_effort > 3) return -1;       // NBLIC.c:733-745
+    const size_t n = (size_t(p_buf[9]) << 8 | p_buf[10]) * (size_t(p_buf[11]) << 8 | p_buf[12]);
     nblic_amd_ctx *c = default_ctx();
     if (!c) return -1;
-    std::lock_guard<std::mutex> g(c->api);
-    return c->serial.decode(p_buf, p_img, *p_height, *p_width, *p_near, k_step, *p_effort, c->device);
+    const unsigned char *streams[1] = {p_buf};
+    unsigned char *imgs[1] = {p_img};
+    size_t lens[1] = {readable_span(p_buf, n + n / 8 + 4096)}, caps[1] = {SIZE_MAX};      // worst case seen: 1.0025 B/px + 20
+    int status[1] = {-1};
+    return nblic_amd_decode_batch(c, 1, streams, lens, imgs, caps, p_height, p_width, p_near, p_effort, status);
 }
 
 int nblic_amd_qencode_batch(nblic_amd_ctx *c, int n_images, const unsigned char *const *imgs, int imgs_on_device,
@@ -1082,9 +1304,9 @@ int nblic_amd_qencode_batch(nblic_amd_ctx *c, int n_images, const unsigned char 
 }
 
 int QNBLICcompress(uint16_t *p_buf, unsigned char *p_img, int height, int width) {
-    if (!size_ok(height, width, kMaxPixels)) return -1;                      // QNBLIC.c:575
     nblic_amd_ctx *c = default_ctx();
     if (!c) return -1;
+    if (!size_ok(height, width, c->max_px)) return -1;                       // QNBLIC.c:575
     const unsigned char *imgs[1] = {p_img};
     uint16_t *outs[1] = {p_buf};
     size_t caps[1] = {SIZE_MAX / 4};                                          // the reference ABI carries no capacity
@@ -1095,8 +1317,14 @@ int QNBLICcompress(uint16_t *p_buf, unsigned char *p_img, int height, int width)
 int QNBLICdecompress(uint16_t *p_buf, unsigned char *p_img, int *p_height, int *p_width) {
     nblic_amd_ctx *c = default_ctx();
     if (!c) return -1;
-    std::lock_guard<std::mutex> g(c->api);
-    return c->serial.qdecode(p_buf, p_img, p_height, p_width, kMaxPixels, c->device);
+    const unsigned char *pb = reinterpret_cast<const unsigned char *>(p_buf);
+    if (readable_span(pb, 8) < 8 || memcmp(pb, "Q0.2", 4) != 0) return -1;    // QNBLIC.c:475-486
+    const size_t n = size_t(p_buf[2]) * size_t(p_buf[3]);
+    const unsigned char *streams[1] = {pb};
+    unsigned char *imgs[1] = {p_img};
+    size_t lens[1] = {readable_span(pb, 2 * n + 32768) & ~size_t(1)}, caps[1] = {SIZE_MAX};
+    int status[1] = {-1}, near = 0, effort = 0;
+    return nblic_amd_decode_batch(c, 1, streams, lens, imgs, caps, p_height, p_width, &near, &effort, status);
 }
 int QNBLICcompressMultiThread(uint16_t *p_buf, unsigned char *p_img, int height, int width) {
     return QNBLICcompress(p_buf, p_img, height, width);                      // QNBLIC.c:872-883: same stream either way

@@ -1,22 +1,26 @@
-// serial_engine.hip -- raster-serial NBLIC engine: one wave per image, model state in LDS.
+// serial_engine.hip -- the raster-serial chains of NBLIC, one wave per image (see serial_engine.h).
 //
-// Used for everything that cannot be replayed per key: NBLICdecompress at any
-// setting, near-lossless encode, and the least-squares efforts 2/3.  Mirrors the reference's
-// fused loop (NBLIC.c:749-908) on the device: context table (8 KB), counter trees (32 KB) and
-// re-mappers (60 KB) sit in the CU's 160 KB LDS; the image, the stream and the least-squares
-// row statistics stay in HBM.
-//
-// The whole wave walks the pixel loop with UNIFORM control flow: the coding of a pixel is a
-// dependent chain, so all 64 lanes carry the same scalars (LDS reads broadcast; global stores are
-// issued by lane 0).  What is not a chain is spread over the lanes: the 43/111-element
-// least-squares statistics (update, per-row pre-pass, system assembly) are one or two elements per
-// lane, and the n x n integer elimination (NBLIC.c:112-161) runs one matrix entry per lane -- within
-// an elimination step every entry only reads the pivot row and the pivot column of the previous
-// step, so the lane-parallel order gives the same integers as the reference's nested loops.
+// A lone wave issues one instruction every ~4 cycles and pays ~50 cycles for every dependent LDS
+// round trip, so these kernels are written for INSTRUCTION COUNT on the chain:
+//   * the scalar part of a pixel (taps, predictor, level, context, residual) is computed by all 64
+//     lanes alike (LDS reads broadcast, every lane stores the same value), with every integer divide
+//     replaced by a table or a reciprocal multiply (model.h NearParams / level_shift_table);
+//   * the least-squares predictor of efforts 2/3 (NBLIC.c:112-283) keeps its statistics in doubles
+//     that hold the reference's integers exactly (lsq_f64.h).  The two regularised systems of a
+//     pixel are solved side by side: lane r of the 16-lane row g holds row r of system g in
+//     registers; the pivot is found with DPP row rotations, the pivot row travels by ds_bpermute,
+//     and each elimination step is one double-carried multiply-divide per column for all rows at
+//     once.  Rows never move: each carries its position, so "first maximum wins" is a key compare.
+//     A pixel whose magnitudes leave the exact range (lsq::Guard) is redone with 64-bit integers;
+//   * the running statistics are updated one or two entries per lane ([s | b | A] order, coalesced
+//     in HBM, the next pixel's columns prefetched a pixel ahead) and handed to the row layout
+//     through 1 KB of LDS.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include <cstring>
 #include <cstdlib>
+#include <cstring>
+
+#include "lsq_f64.h"
 #include "model.h"
 #include "serial_engine.h"
 
@@ -25,48 +29,41 @@ namespace nblic {
 typedef long long i64;
 typedef unsigned long long u64;
 
-constexpr int kLsqMaxN = 10, kLsqMaxM = 1 + kLsqMaxN + kLsqMaxN * kLsqMaxN;
-constexpr int kFb1 = 12, kFb2 = 2, kFb3 = 10, kDecayS = 3, kDecayV = 5;
-constexpr i64 kBiasInit = 8, kBiasMax = 4096, kBiasCoef = 21;
-constexpr int kRowCache = 16384;                 // widest image whose three tap rows fit next to the model in LDS
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }     // one wave per block: orders LDS traffic between lanes
 
-__device__ __forceinline__ i64 mulw(i64 a, i64 b) { return i64(u64(a) * u64(b)); }    // wrapping, NBLIC.c:139
-__device__ __forceinline__ i64 abs64(i64 v) { return v < 0 ? -v : v; }
-__device__ __forceinline__ i64 clip64(i64 v, i64 lo, i64 hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ i64 decay(i64 v, int ab) { return (mulw(v, ab - 1) + ab / 2) / ab; }   // NBLIC.c:199,273-279
+// Pointers read out of the job record are generic to the compiler; telling it they are global memory
+// turns flat_load / flat_store into global_load / global_store and keeps LDS out of their waits.
+#define NB_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ NB_GLOBAL T *gp(T *p) { return (NB_GLOBAL T *)p; }
 
-struct SerialArgs {
-    uint8_t *img; uint8_t *stream; size_t stream_cap;
-    int h, w, near, k_step, effort, decode;
-    i64 *stats; long *len_out;
-};
-
-// ---- range coder on the device (NBLIC.c:527-586) -------------------------------------------
-struct DevCoder {
-    uint8_t *p, *end;
-    uint32_t lo, hi, window;
-    bool overflow;
-    bool store;                 // only one lane of the wave writes the stream
-};
-
-template <bool DEC>
-__device__ __forceinline__ int coder_bin(DevCoder &rc, int bin, uint32_t prob) {
-    uint32_t cut = rc.lo + uint32_t((u64(rc.hi - rc.lo) * prob) >> 12);
-    if (DEC) bin = rc.window <= cut;
-    if (bin) rc.hi = cut; else rc.lo = cut + 1;
-    while (((rc.lo ^ rc.hi) >> 24) == 0) {
-        if (rc.p < rc.end) {
-            if (DEC) rc.window = (rc.window << 8) | *rc.p; else if (rc.store) *rc.p = uint8_t(rc.hi >> 24);
-        } else { rc.overflow = true; if (DEC) rc.window <<= 8; }
-        rc.p++;
-        rc.lo <<= 8; rc.hi = (rc.hi << 8) | 0xFFu;
-    }
-    return bin;
+// ---- cross-lane moves of doubles ------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kRor1 = 0x121, kRor2 = 0x122, kRor4 = 0x124, kRor8 = 0x128;   // rotate right inside each 16-lane row
+__device__ __forceinline__ double row_max(double v) {
+    v = fmax(v, dpp_f64<kRor1>(v)); v = fmax(v, dpp_f64<kRor2>(v));
+    v = fmax(v, dpp_f64<kRor4>(v)); v = fmax(v, dpp_f64<kRor8>(v));
+    return v;
+}
+__device__ __forceinline__ double row_sum(double v) {
+    v += dpp_f64<kRor1>(v); v += dpp_f64<kRor2>(v); v += dpp_f64<kRor4>(v); v += dpp_f64<kRor8>(v);
+    return v;
+}
+// value of lane (byte_addr / 4)
+__device__ __forceinline__ double fetch_f64(double v, int byte_addr) {
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 
-// P(bin==1) = floor(4096 * c1 / (c0 + c1)) (NBLIC.c:621-625) without the integer-divide expansion:
-// both operands are < 2^14, so the float reciprocal estimate is off by less than one and a single
-// remainder check makes it exact.
+// P(bin==1) = floor(4096 * c1 / (c0 + c1)) (NBLIC.c:621-625): both operands are < 2^14, so the float
+// reciprocal estimate is off by less than one and a single remainder check makes it exact.
 __device__ __forceinline__ int prob_one(int c0, int c1) {
     const int sum = c0 + c1, n = c1 << 12;
     int q = int(float(n) * __builtin_amdgcn_rcpf(float(sum)));
@@ -75,203 +72,480 @@ __device__ __forceinline__ int prob_one(int c0, int c1) {
     return q;
 }
 
-// ---- the engine's LDS image ------------------------------------------------------------------
-struct Lds {
-    int     ctx[kContexts];
-    int     c0[kLevels][kTreeNodes], c1[kLevels][kTreeNodes];
-    int     count[512][kMapSyms];
+// ---- LDS images --------------------------------------------------------------------------------
+struct LsqLds {
+    double D[128];                           // statistics of the pixel about to be predicted: [s | b | A] (E + F)
+    int8_t vn8[16];                          // regressors 0..9 (tap - 128); [14] = 0; [15] = x' - 128
+    i64 Mi[lsq::kMaxN][lsq::kMaxN + 1];      // integer redo of a pixel (rare): augmented system, terms
+    i64 termi[lsq::kMaxN];
+};
+struct ModelLds {
+    int ctx[kContexts];
+    uint16_t qlut[208];                      // activity (clipped to 200) -> qu | qv << 4 | qw << 8
+    uint32_t rec_ring[64];
+    uint16_t pxs_ring[64];
+    LsqLds q;
+};
+struct DecodeLds {
+    int ctx[kContexts];
+    uint16_t qlut[208];
+    uint32_t cnt[kLevels][kTreeNodes];       // c0 | c1 << 16 (both <= 8224)
+    int count[512][kMapSyms];
     uint8_t rank_of[512][kMapSyms], sym_at[512][kMapSyms];
-    // least squares (efforts 2/3): vectors are [s | b(n) | A(n x n)] (NBLIC.c:213-215)
-    i64     E[kLsqMaxM + 1];                     // statistics of the current row so far
-    i64     D[kLsqMaxM + 1];                     // E + F at the current pixel
-    i64     M[kLsqMaxN][kLsqMaxN + 1];           // augmented system [A | b]
-    i64     vn[kLsqMaxN];
-    i64     term[kLsqMaxN];
-    // the three image rows the causal taps can touch, as a ring (row r lives at r % 3): taps come
-    // from LDS instead of a store -> fence -> load round trip through L2 for every pixel
-    uint8_t rows[3][kRowCache];
+    uint32_t sbuf[256];                      // 1 KB window of the stream, two halves
+    LsqLds q;
 };
 
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }     // one wave per block: orders LDS traffic between lanes
+// activity -> (qu, qv, qw) (model.h quantise) as a table: the interpolation divides by a level gap
+__device__ void fill_qlut(uint16_t *qlut) {
+    for (int d = int(threadIdx.x); d < 208; d += 64) {
+        const Level L = quantise(d < 200 ? d : 200);
+        qlut[d] = uint16_t(L.qu | (L.qv << 4) | (L.qw << 8));
+    }
+}
+__device__ __forceinline__ Level level_from(uint16_t e) { return Level{e & 15, (e >> 4) & 15, e >> 8}; }
 
-// ---- least-squares predictor, lane-parallel ----------------------------------------------------
-// Q12 prediction from the regularised normal equations (NBLIC.c:210-239 with the solve of :112-161).
-// Uniform result (every lane returns the same values).
-__device__ int lsq_predict_wave(Lds &S, int n, int m, const i64 *F, i64 bias, i64 *px_q12) {
+// ---- least squares, integer redo (NBLIC.c:112-161, :210-239): all 64 lanes, one system ------------
+__device__ __forceinline__ i64 mulw(i64 a, i64 b) { return i64(u64(a) * u64(b)); }
+__device__ __forceinline__ i64 abs64(i64 v) { return v < 0 ? -v : v; }
+
+__device__ __noinline__ int lsq_solve_int(LsqLds &S, int n, i64 bias, i64 *px_q12) {
     const int lane = int(threadIdx.x), cols = n + 1;
-    for (int k = lane; k < m; k += 64) S.D[k] = k ? S.E[k] + F[k] : 0;
     wave_sync();
     for (int e = lane; e < n * cols; e += 64) {
         const int i = e / cols, j = e - i * cols;
-        S.M[i][j] = j == n ? S.D[1 + i] + bias * (1 << kFb3) : S.D[1 + n + i * n + j] + (i == j ? bias * n : 0);
+        S.Mi[i][j] = j == n ? i64(S.D[1 + i]) + bias * (1 << lsq::kFb3) : i64(S.D[1 + n + i * n + j]) + (i == j ? bias * n : 0);
     }
     wave_sync();
-    for (int k = 0; k + 1 < n; k++) {                                   // forward elimination, partial pivoting
+    for (int k = 0; k + 1 < n; k++) {
         int piv = k;
-        i64 best = abs64(S.M[k][k]);
-        for (int i = k + 1; i < n; i++) { const i64 v = abs64(S.M[i][k]); if (v > best) { best = v; piv = i; } }   // strict: first maximum wins
+        i64 best = abs64(S.Mi[k][k]);
+        for (int i = k + 1; i < n; i++) { const i64 v = abs64(S.Mi[i][k]); if (v > best) { best = v; piv = i; } }
+        wave_sync();
         if (piv != k) {
-            for (int j = lane; j < cols; j += 64) { const i64 t = S.M[k][j]; S.M[k][j] = S.M[piv][j]; S.M[piv][j] = t; }
+            for (int j = lane; j < cols; j += 64) { const i64 t = S.Mi[k][j]; S.Mi[k][j] = S.Mi[piv][j]; S.Mi[piv][j] = t; }
             wave_sync();
         }
-        const i64 d = S.M[k][k];
+        const i64 d = S.Mi[k][k];
         if (d == 0) return 0;
         i64 upd[2]; int cnt = 0;
         for (int e = lane; e < n * cols; e += 64) {
             const int i = e / cols, j = e - i * cols;
-            upd[cnt++] = (i > k && j > k) ? S.M[i][j] - mulw(S.M[k][j], S.M[i][k]) / d : 0;
+            upd[cnt++] = (i > k && j > k) ? S.Mi[i][j] - mulw(S.Mi[k][j], S.Mi[i][k]) / d : 0;
         }
-        wave_sync();                                                   // every lane has read column k before it is cleared
+        wave_sync();
         cnt = 0;
         for (int e = lane; e < n * cols; e += 64) {
             const int i = e / cols, j = e - i * cols;
-            if (i > k && j > k) S.M[i][j] = upd[cnt]; else if (i > k && j == k) S.M[i][j] = 0;
+            if (i > k && j > k) S.Mi[i][j] = upd[cnt]; else if (i > k && j == k) S.Mi[i][j] = 0;
             cnt++;
         }
         wave_sync();
     }
-    for (int k = n - 1; k > 0; k--) {                                   // back substitution on b only
-        const i64 d = S.M[k][k];
+    for (int k = n - 1; k > 0; k--) {
+        const i64 d = S.Mi[k][k];
         if (d == 0) return 0;
-        for (int i = lane; i < k; i += 64) { S.M[i][n] -= mulw(S.M[k][n], S.M[i][k]) / d; S.M[i][k] = 0; }
+        wave_sync();
+        for (int i = lane; i < k; i += 64) { S.Mi[i][n] -= mulw(S.Mi[k][n], S.Mi[i][k]) / d; S.Mi[i][k] = 0; }
         wave_sync();
     }
     for (int k = lane; k < n; k += 64) {
-        const i64 d = S.M[k][k];
-        S.term[k] = (mulw(mulw(S.M[k][n], S.vn[k]), 1 << kFb2) + (d >> 1)) / d;
+        const i64 d = S.Mi[k][k];
+        S.termi[k] = (mulw(mulw(S.Mi[k][n], i64(S.vn8[k])), 1 << lsq::kFb2) + (d >> 1)) / d;
     }
     wave_sync();
-    i64 px = i64(kMid) << kFb1;
-    for (int k = 0; k < n; k++) px += S.term[k];
+    i64 px = i64(kMid) << lsq::kFb1;
+    for (int k = 0; k < n; k++) px += S.termi[k];
     wave_sync();
-    *px_q12 = clip64(px, 0, i64(kMaxVal) << kFb1);
+    *px_q12 = px;
     return 1;
 }
 
-// fold the newly coded pixel into the running statistics (NBLIC.c:242-283), one or two entries per lane
-__device__ void lsq_update_wave(Lds &S, int n, int m, i64 *B, int x, i64 s_curr, i64 s_sum) {
-    const i64 xc = x - kMid;
-    s_sum = clip64(s_sum + (1 << kFb1), 1 << kFb1, 16 << kFb1);
-    const i64 half = s_sum >> 1;
-    for (int k = int(threadIdx.x); k < m; k += 64) {
-        i64 sample;
-        if (k == 0) sample = s_curr;
-        else if (k <= n) sample = (mulw(xc * S.vn[k - 1], i64(1) << (4 + kFb1 + kFb1)) + half) / s_sum;
-        else { const int r = (k - 1 - n) / n, c = (k - 1 - n) - r * n; sample = (mulw(S.vn[r] * S.vn[c], i64(1) << (4 + kFb2 + kFb1)) + half) / s_sum; }
-        const int ab = k ? kDecayV : kDecayS;
-        const i64 b = decay(B[k], ab) + sample;
-        B[k] = b;
-        S.E[k] = decay(S.E[k], ab) + b;
-    }
-    wave_sync();
-}
-
-// once per row: right-to-left accumulation of the row-above statistics (NBLIC.c:186-204); a lane owns a channel
-__device__ void lsq_row_prepare_wave(int m, i64 *Frow, const i64 *Brow, int w) {
-    for (int k = int(threadIdx.x); k < m; k += 64) {
-        const int ab = k ? kDecayV : kDecayS;
-        i64 carry = 0;
-        for (int j = w - 1; j >= 0; j--) {
-            const i64 f = carry + Brow[size_t(j) * m + k];
-            Frow[size_t(j) * m + k] = f;
-            carry = decay(f, ab);
+// ---- least squares in registers: the pixel's two systems side by side ---------------------------
+// Lane layout: row = lane & 15 of system (lane >> 4) & 1 (the upper half of the wave mirrors the lower).
+// M[0..N) = the row of A, M[N] = its right-hand side.  Returns the Q12 prediction of the lane's system
+// in every lane of its 16-lane row; `ok` false = a pivot was zero (NBLIC.c:118).
+template <int N>
+__device__ __forceinline__ double lsq_solve_rows(double (&M)[N + 1], const int row, const int row_base4, const int8_t *vn8,
+                                                 lsq::Guard &g, int &ok) {
+    // (flags are ints in vector registers: as booleans they would each pin a scalar register pair for the whole solve)
+    const int live = row < N;
+    int pos = row, at_sum = 0;
+    int at[N];
+    double diag = 1.0;
+    ok = 1;
+#pragma unroll
+    for (int k = 0; k + 1 < N; k++) {
+        // pivot: largest |entry| of column k among the rows at positions >= k, first position wins (NBLIC.c:121-127)
+        const double key = row_max((live & (pos >= k)) ? fma(fabs(M[k]), 256.0, double((15 - pos) * 16 + row)) : -1.0);
+        const int tag = int(fma(-256.0, floor(key * (1.0 / 256.0)), key));
+        const int c = tag & 15, pc = 15 - (tag >> 4);
+        at[k] = c; at_sum += c;
+        pos = pos == k ? pc : pos;                                       // the row that sat at k takes the pivot's place
+        pos = (live & (row == c)) ? k : pos;
+        const int src = row_base4 | (c << 2);
+        const double d = fetch_f64(M[k], src);
+        diag = pos == k ? d : diag;
+        ok &= int(d != 0.0);
+        const double rs = lsq::recip_short(d);
+        const double l = (live & (pos > k)) ? M[k] : 0.0;                // rows already placed take no part: their quotient is 0
+#pragma unroll
+        for (int j = k + 1; j <= N; j++) {
+            M[j] -= lsq::muldiv_trunc(fetch_f64(M[j], src), l, d, rs, g);
+            g.entry = fmax(g.entry, fabs(M[j]));
         }
     }
-    __threadfence_block();
-    wave_sync();
+    at[N - 1] = N * (N - 1) / 2 - at_sum;
+    diag = (live & (pos == N - 1)) ? M[N - 1] : diag;
+#pragma unroll
+    for (int k = N - 1; k > 0; k--) {                                     // back substitution on the right-hand side (NBLIC.c:148-158)
+        const int src = row_base4 | (at[k] << 2);
+        const double d = fetch_f64(diag, src), bk = fetch_f64(M[N], src);
+        ok &= int(d != 0.0);
+        const double l = (live & (pos < k)) ? M[k] : 0.0;
+        M[N] -= lsq::muldiv_trunc(bk, l, d, lsq::recip_short(d), g);
+        g.entry = fmax(g.entry, fabs(M[N]));
+    }
+    const int v = vn8[live ? pos : 14];
+    const double t = lsq::term(live ? M[N] : 0.0, v, diag, g);            // NBLIC.c:233-236
+    return double(kMid << lsq::kFb1) + row_sum(live ? t : 0.0);
 }
 
-// ---- the engine --------------------------------------------------------------------------------
-template <bool DEC>
-__device__ void run_engine(const SerialArgs &a, Lds &S) {
-    const int w = a.w, h = a.h, near = a.near, k_step = a.k_step;
-    const int n = a.effort == 2 ? 6 : (a.effort == 3 ? 10 : 0);                    // N_LIST, NBLIC.c:88
-    const int m = 1 + n + n * n;
-    const bool lane0 = threadIdx.x == 0;
-    uint8_t *img = a.img;
-    i64 *Brow = a.stats, *Frow = a.stats + size_t(w) * m;
-    i64 bias = kBiasInit;
+// Per-lane description of the one or two statistics entries a lane maintains ([s | b(n) | A(n x n)] order).
+template <int N>
+struct LsqEntries {
+    static constexpr int kM = 1 + N + N * N, kSlots = kM > 64 ? 2 : 1, kStride = kM > 64 ? 128 : 64;
+    int ia[kSlots], ib[kSlots];              // vn8 indices whose product is the entry's sample (b: x' x vn, A: vn x vn)
+    double scale[kSlots], ab[kSlots], abm1[kSlots], abh[kSlots], rab[kSlots];
+    bool active[kSlots];
+    __device__ void init(int lane) {
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            const int k = lane + 64 * s;
+            active[s] = k < kM;
+            const int kk = active[s] ? k : 0;
+            if (kk == 0) { ia[s] = 14; ib[s] = 14; }
+            else if (kk <= N) { ia[s] = 15; ib[s] = kk - 1; }
+            else { ia[s] = (kk - 1 - N) / N; ib[s] = (kk - 1 - N) - ia[s] * N; }
+            scale[s] = kk <= N ? lsq::kScaleB : lsq::kScaleA;
+            const int a = kk ? lsq::kDecayV : lsq::kDecayS;
+            ab[s] = double(a); abm1[s] = double(a - 1); abh[s] = double(a / 2); rab[s] = lsq::kShort / double(a);
+        }
+    }
+    __device__ __forceinline__ double decay(double v, int s) const { return lsq::div_trunc(fma(v, abm1[s], abh[s]), ab[s], rab[s]); }
+};
 
-    DevCoder rc{a.stream + kHeaderBytes, a.stream + a.stream_cap, 0u, 0xFFFFFFFFu, 0u, false};
-    rc.store = lane0;
-    if (DEC) for (int k = 0; k < 4; k++) rc.window = (rc.window << 8) | *rc.p++;
+// once per row: right-to-left accumulation of the column sums (NBLIC.c:186-204); a lane owns its entries
+template <int N>
+__device__ void lsq_row_prepare(const LsqEntries<N> &en, NB_GLOBAL double *F, NB_GLOBAL const double *B, int w, int lane) {
+    using T = LsqEntries<N>;
+#pragma unroll
+    for (int s = 0; s < T::kSlots; s++) {
+        if (!en.active[s]) continue;
+        const size_t k = size_t(lane + 64 * s);
+        double carry = 0.0;
+        int j = w - 1;
+        for (; j >= 3; j -= 4) {                                          // four loads in flight per step of the chain
+            const double b0 = B[size_t(j) * T::kStride + k], b1 = B[size_t(j - 1) * T::kStride + k];
+            const double b2 = B[size_t(j - 2) * T::kStride + k], b3 = B[size_t(j - 3) * T::kStride + k];
+            double f = carry + b0; F[size_t(j) * T::kStride + k] = f; carry = en.decay(f, s);
+            f = carry + b1; F[size_t(j - 1) * T::kStride + k] = f; carry = en.decay(f, s);
+            f = carry + b2; F[size_t(j - 2) * T::kStride + k] = f; carry = en.decay(f, s);
+            f = carry + b3; F[size_t(j - 3) * T::kStride + k] = f; carry = en.decay(f, s);
+        }
+        for (; j >= 0; j--) { const double f = carry + B[size_t(j) * T::kStride + k]; F[size_t(j) * T::kStride + k] = f; carry = en.decay(f, s); }
+    }
+}
 
-    const bool cached = w <= kRowCache;
-    auto pix = [&](int r, int c) {
-        return cached ? int(S.rows[r % 3][c]) : int(img[size_t(r) * size_t(w) + size_t(c)]);
-    };
+// The least-squares state of one image walk, shared by the encoder's model kernel and the decoder.
+template <int N>
+struct LsqWalk {
+    using T = LsqEntries<N>;
+    LsqEntries<N> en;
+    double E[T::kSlots], Bj[T::kSlots], Fj[T::kSlots], Bn[T::kSlots], Fn[T::kSlots];
+    NB_GLOBAL double *Bst, *Fst;
+    int bias, b1, b2, lane, row, row_base4, w;
+    i64 p1, p2;
+    bool ok1, ok2;
+
+    __device__ void init(double *stats, int w_, int lane_) {
+        lane = lane_; w = w_; row = lane & 15; row_base4 = (lane & 48) << 2;
+        Bst = gp(stats); Fst = gp(stats) + size_t(w) * T::kStride;
+        bias = lsq::kBiasInit;
+        en.init(lane);
+    }
+    __device__ __forceinline__ void load_cols(int j, double (&b)[T::kSlots], double (&f)[T::kSlots]) const {
+        const int jj = j < w ? j : w - 1;                                 // the prefetch past the row end re-reads the last column
+#pragma unroll
+        for (int s = 0; s < T::kSlots; s++) {
+            const size_t at = size_t(jj) * T::kStride + size_t(en.active[s] ? lane + 64 * s : 0);
+            b[s] = Bst[at]; f[s] = Fst[at];
+        }
+    }
+    __device__ void row_begin(LsqLds &S) {
+        lsq_row_prepare<N>(en, Fst, Bst, w, lane);
+        __threadfence_block();
+        wave_sync();
+        load_cols(0, Bj, Fj);
+#pragma unroll
+        for (int s = 0; s < T::kSlots; s++) { E[s] = 0.0; if (en.active[s]) S.D[lane + 64 * s] = Fj[s]; }
+        wave_sync();
+    }
+    // predictions of pixel j from S.D and S.vn8 (both complete and synchronised)
+    __device__ __forceinline__ void predict(LsqLds &S, int j) {
+        load_cols(j + 1, Bn, Fn);                                         // next pixel's columns: a whole pixel ahead of their use
+        lsq::bias_pair(bias, b1, b2);
+        const int bs = (lane & 16) ? b2 : b1;
+        const int r = row < N ? row : N - 1;
+        double M[N + 1];
+#pragma unroll
+        for (int c = 0; c < N; c++) M[c] = S.D[1 + N + r * N + c];
+        M[N] = S.D[1 + r] + double(bs << lsq::kFb3);
+#pragma unroll
+        for (int c = 0; c < N; c++) M[c] = (row == c) ? M[c] + double(bs * N) : M[c];
+        if (row >= N) {
+#pragma unroll
+            for (int c = 0; c <= N; c++) M[c] = 0.0;
+        }
+        lsq::Guard g;
+        int ok;
+        const double p = lsq_solve_rows<N>(M, row, row_base4, S.vn8, g, ok);
+        const double pc = p < 0.0 ? 0.0 : (p > double(kMaxVal << lsq::kFb1) ? double(kMaxVal << lsq::kFb1) : p);
+        const int pi = int(pc);
+        const u64 bad = __ballot(!g.ok());
+        p1 = __builtin_amdgcn_readlane(pi, 0); p2 = __builtin_amdgcn_readlane(pi, 16);
+        const u64 okm = __ballot(ok != 0);
+        ok1 = (okm & 1ull) != 0; ok2 = ((okm >> 16) & 1ull) != 0;
+        if (bad & 0xFFFFFFFFull) {                                       // magnitudes left the exact range: integers decide (rare)
+            i64 q1 = 0, q2 = 0;
+            ok1 = lsq_solve_int(S, N, b1, &q1) != 0;
+            ok2 = lsq_solve_int(S, N, b2, &q2) != 0;
+            const i64 top = i64(kMaxVal) << lsq::kFb1;
+            p1 = q1 < 0 ? 0 : (q1 > top ? top : q1); p2 = q2 < 0 ? 0 : (q2 > top ? top : q2);
+        }
+    }
+    // fold the coded pixel in (NBLIC.c:242-283, :882-893) and publish the next pixel's statistics; S.vn8[15] = x' - 128 is set
+    __device__ __forceinline__ void update(LsqLds &S, int j, int xr, i64 p1_used) {
+        const i64 xq = i64(xr) << lsq::kFb1;
+        const i64 e1 = abs64(p1_used - xq);
+        const double s_curr = double(e1);
+        const double e0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(E[0]), 0), __builtin_amdgcn_readlane(__double2loint(E[0]), 0));
+        const double f0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Fj[0]), 0), __builtin_amdgcn_readlane(__double2loint(Fj[0]), 0));
+        const double s_sum = (e0 + f0) + floor(s_curr * 1.5);
+        const double sw = lsq::sample_weight(s_sum), rs = lsq::recip_short(sw);
+#pragma unroll
+        for (int s = 0; s < T::kSlots; s++) {
+            const int prod = int(S.vn8[en.ia[s]]) * int(S.vn8[en.ib[s]]);
+            double sample = lsq::sample_entry(prod, en.scale[s], sw, rs);
+            if (s == 0) sample = lane == 0 ? s_curr : sample;
+            const double b = en.decay(Bj[s], s) + sample;
+            if (en.active[s]) Bst[size_t(j) * T::kStride + size_t(lane + 64 * s)] = b;
+            E[s] = en.decay(E[s], s) + b;
+        }
+        if (ok1 && ok2) bias = (abs64(p1 - xq) > abs64(p2 - xq)) ? b2 : b1;
+#pragma unroll
+        for (int s = 0; s < T::kSlots; s++) {
+            if (en.active[s]) S.D[lane + 64 * s] = E[s] + Fn[s];
+            Bj[s] = Bn[s]; Fj[s] = Fn[s];
+        }
+    }
+};
+
+// pack the ten regressors (a,b,c,d,e,f,t,h,q,g, NBLIC.c:164-183) as bytes and store them with one LDS write per word
+__device__ __forceinline__ void store_regressors(int8_t *vn8, const Taps &t) {
+    auto b = [](int v) { return uint32_t(v - kMid) & 0xFFu; };
+    uint32_t *w = reinterpret_cast<uint32_t *>(vn8);
+    w[0] = b(t.a) | (b(t.b) << 8) | (b(t.c) << 16) | (b(t.d) << 24);
+    w[1] = b(t.e) | (b(t.f) << 8) | (b(t.t) << 16) | (b(t.h) << 24);
+    w[2] = b(t.q) | (b(t.g) << 8);
+}
+
+// ---- encoder: the serial model stage (prediction, context bias, quantisation) ------------------
+// CACHED: the three rows the taps can touch live in LDS (a ring, row r at r % 3), so a pixel's twelve
+// taps are twelve LDS reads issued together; otherwise (rows wider than the LDS left over) they come
+// from the reconstruction in memory.  The two variants are separate code: one generic accessor would
+// turn every tap into a flat load with a branch and a full wait of its own.
+template <int N, bool CACHED>
+__device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const SerialJob &J, const int rs) {
+    const int w = J.w, h = J.h, lane = int(threadIdx.x);
+    const NearParams np = near_params(J.near);
+    const auto img = gp(J.img);
+    const auto recon = gp(J.recon);
+    const auto rec1 = gp(J.rec1);
+    const auto pxs = gp(J.pxs);
+    LsqWalk<N> lw;
+    if constexpr (N > 0) lw.init(J.stats, w, lane);
 
     for (int i = 0; i < h; i++) {
-        int err = 0;
-        if (cached && !DEC) {                                                      // encoder: the row's ORIGINAL pixels; each is replaced by its reconstruction once coded
-            for (int c = int(threadIdx.x); c < w; c += 64) S.rows[i % 3][c] = img[size_t(i) * size_t(w) + size_t(c)];
+        uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
+        const size_t row_at = size_t(i) * size_t(w);
+        if (CACHED) {                                                    // the row's ORIGINAL pixels; each is replaced by its reconstruction once coded
+            for (int c = lane; c < w; c += 64) r0[c] = img[row_at + c];
             wave_sync();
         }
-        if (n > 0) {                                                               // NBLIC.c:817-820
-            for (int k = int(threadIdx.x); k < m; k += 64) S.E[k] = 0;
-            lsq_row_prepare_wave(m, Frow, Brow, w);
-        }
+        auto pix = [&](int r, int c) {
+            if (CACHED) return int((r == i ? r0 : (r == i - 1 ? r1 : r2))[c]);
+            return int(recon[size_t(r) * size_t(w) + size_t(c)]);
+        };
+        if constexpr (N > 0) lw.row_begin(S.q);
+        int err = 0;
         for (int j = 0; j < w; j++) {
-            Taps t = sample_taps(pix, w, i, j);
-            i64 b1 = 0, b2 = 0, p1 = 0, p2 = 0;
-            int ok1 = 0, ok2 = 0, px0;
-            i64 *B = nullptr, *F = nullptr;
-            if (n > 0) {                                                           // NBLIC.c:831-846
-                if (threadIdx.x < unsigned(n)) {
-                    const int order[kLsqMaxN] = {t.a, t.b, t.c, t.d, t.e, t.f, t.t, t.h, t.q, t.g};
-                    int v = order[0];
-                    for (int k = 1; k < kLsqMaxN; k++) if (int(threadIdx.x) == k) v = order[k];
-                    S.vn[threadIdx.x] = v - kMid;
-                }
+            const Taps t = sample_taps(pix, w, i, j);
+            const int x = CACHED ? int(r0[j]) : int(img[row_at + j]);
+            int px0;
+            i64 p1_used = 0;
+            if constexpr (N > 0) {
+                if (lane == 0) store_regressors(S.q.vn8, t);
                 wave_sync();
-                B = Brow + size_t(j) * m; F = Frow + size_t(j) * m;
-                b1 = bias * kBiasCoef / (kBiasCoef + 1);
-                b2 = bias * (kBiasCoef + 1) / kBiasCoef;
-                b1 = clip64(clip64(b1, -1, bias - 1), 0, kBiasMax);
-                b2 = clip64(clip64(b2, bias + 1, kBiasMax + 1), 0, kBiasMax);
-                ok1 = lsq_predict_wave(S, n, m, F, b1, &p1);
-                ok2 = lsq_predict_wave(S, n, m, F, b2, &p2);
+                lw.predict(S.q, j);
+                if (lw.ok1) { px0 = int((lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1); p1_used = lw.p1; }
+                else { px0 = predict(t); p1_used = i64(px0) << lsq::kFb1; }
+            } else {
+                px0 = predict(t);
             }
-            if (ok1) px0 = int((p1 + (1 << (kFb1 - 1))) >> kFb1);
-            else { px0 = predict(t); p1 = i64(px0) << kFb1; }
+            const int delta = activity(t, err);
+            const Level L = level_from(S.qlut[delta < 200 ? delta : 200]);
+            const int adr = context_address(t, L.qu, px0);
+            const int v = S.ctx[adr];
+            const int sign = bias_sign(v), px = bias_apply(v, px0);
+            const int y = residual_to_symbol(x, px, sign, np);
+            const int xr = symbol_to_pixel(y, px, sign, np);
+            err = clip_err(xr, px0);
+            S.ctx[adr] = bias_update(v, err);
+            if (CACHED) r0[j] = uint8_t(xr); else recon[row_at + j] = uint8_t(xr);
+            S.rec_ring[j & 63] = pack_s1(px0, adr, L);
+            S.pxs_ring[j & 63] = uint16_t(px | (sign << 8));
+            if ((j & 63) == 63 || j == w - 1) {                          // a lane per record: coalesced stores
+                const int base = j & ~63;
+                if (base + lane <= j) { rec1[row_at + base + lane] = S.rec_ring[lane]; pxs[row_at + base + lane] = S.pxs_ring[lane]; }
+            }
+            if constexpr (N > 0) {
+                if (lane == 0) S.q.vn8[15] = int8_t(xr - kMid);
+                wave_sync();
+                lw.update(S.q, j, xr, p1_used);
+                wave_sync();
+            }
+        }
+        if (CACHED && J.recon) {
+            wave_sync();
+            for (int c = lane; c < w; c += 64) recon[row_at + c] = r0[c];
+        }
+    }
+}
 
-            Level L = quantise(activity(t, err));
-            int adr = context_address(t, L.qu, px0);
-            int v = S.ctx[adr];
-            int sign = bias_sign(v), px = bias_apply(v, px0);
-            int mk = px * 2 + sign;
+template <int N>
+__global__ void __launch_bounds__(64) k_serial_model(const SerialJob *__restrict__ jobs, int dyn_bytes) {
+    __shared__ ModelLds S;
+    extern __shared__ __align__(16) uint8_t rows[];
+    const SerialJob &J = jobs[blockIdx.x];
+    const int lane = int(threadIdx.x);
+    for (int k = lane; k < kContexts; k += 64) S.ctx[k] = 0;
+    fill_qlut(S.qlut);
+    if (lane < 16) S.q.vn8[lane] = 0;
+    wave_sync();
+    const int rs = (J.w + 15) & ~15;
+    if (3 * rs <= dyn_bytes) model_body<N, true>(S, rows, J, rs);
+    else model_body<N, false>(S, rows, J, rs);
+}
 
-            auto step = [&](int qu, int qv, int node, int bin) {                   // NBLIC.c:628-637
-                int u0 = S.c0[qu][node], u1 = S.c1[qu][node], v0 = S.c0[qv][node], v1 = S.c1[qv][node];
-                int prob = mix_prob(prob_one(u0, u1), prob_one(v0, v1), L.qw);
-                bin = coder_bin<DEC>(rc, bin, uint32_t(prob));
-                Counter cu{u0, u1};
-                counter_add(cu, bin, kWeightOne - L.qw);
-                if (qu == qv) counter_add(cu, bin, L.qw);                          // same counter takes both weights
-                S.c0[qu][node] = cu.c0; S.c1[qu][node] = cu.c1;
+// ---- decoder: the whole NBLIC loop (NBLIC.c:749-908 with decode = 1) ----------------------------
+// The stream is staged through LDS 512 bytes at a time so that a renormalisation byte costs an LDS
+// read, not a trip to HBM in the middle of the chain.
+struct StreamWindow {
+    const uint8_t *base; size_t len, pos;      // pos = next byte to consume
+    uint32_t *sbuf;
+    bool overrun;
+    __device__ void fill_half(size_t from) {   // bytes [from, from + 512) -> sbuf half (from / 512) & 1; from is a multiple of 512
+        const auto src = gp(reinterpret_cast<const uint32_t *>(base));       // device copies are 16-byte aligned and padded by 2 KB
+        const size_t word = from / 4 + threadIdx.x * 2;
+        sbuf[((from >> 9) & 1) * 128 + threadIdx.x * 2] = src[word];
+        sbuf[((from >> 9) & 1) * 128 + threadIdx.x * 2 + 1] = src[word + 1];
+    }
+    __device__ void start(const uint8_t *b, size_t n, size_t at, uint32_t *buf) {
+        base = b; len = n; pos = at; sbuf = buf; overrun = false;
+        fill_half(0); fill_half(512);
+        wave_sync();
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (pos >= len) overrun = true;
+        const uint32_t byte = (sbuf[(pos & 1023) >> 2] >> (8 * (pos & 3))) & 0xFFu;
+        pos++;
+        if ((pos & 511) == 0) {                 // a half has been consumed: refill it with the bytes 1024 ahead of its start
+            wave_sync();
+            fill_half(pos + 512);
+            wave_sync();
+        }
+        return byte;
+    }
+};
+
+template <int N, bool CACHED>
+__device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const SerialJob &J, const int rs) {
+    const int w = J.w, h = J.h, lane = int(threadIdx.x), k_step = J.k_step;
+    const NearParams np = near_params(J.near);
+    const uint64_t ktab = level_shift_table(k_step);
+    const auto out = gp(J.recon);
+    LsqWalk<N> lw;
+    if constexpr (N > 0) lw.init(J.stats, w, lane);
+    StreamWindow sw;
+    sw.start(J.stream, J.stream_len, kHeaderBytes, S.sbuf);
+    uint32_t lo = 0u, hi = 0xFFFFFFFFu, window = 0u;                    // NBLIC.c:536-549
+    for (int k = 0; k < 4; k++) window = (window << 8) | sw.next();
+
+    for (int i = 0; i < h; i++) {
+        uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
+        auto pix = [&](int r, int c) {
+            if (CACHED) return int((r == i ? r0 : (r == i - 1 ? r1 : r2))[c]);
+            return int(out[size_t(r) * size_t(w) + size_t(c)]);
+        };
+        if constexpr (N > 0) lw.row_begin(S.q);
+        int err = 0;
+        const size_t row_at = size_t(i) * size_t(w);
+        for (int j = 0; j < w; j++) {
+            const Taps t = sample_taps(pix, w, i, j);
+            int px0;
+            i64 p1_used = 0;
+            if constexpr (N > 0) {
+                if (lane == 0) store_regressors(S.q.vn8, t);
+                wave_sync();
+                lw.predict(S.q, j);
+                if (lw.ok1) { px0 = int((lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1); p1_used = lw.p1; }
+                else { px0 = predict(t); p1_used = i64(px0) << lsq::kFb1; }
+            } else {
+                px0 = predict(t);
+            }
+            const int delta = activity(t, err);
+            const Level L = level_from(S.qlut[delta < 200 ? delta : 200]);
+            const int adr = context_address(t, L.qu, px0);
+            const int v = S.ctx[adr];
+            const int sign = bias_sign(v), px = bias_apply(v, px0);
+            const int mk = px * 2 + sign;
+            const int z = walk_symbol_t(k_step, ktab, L.qu, L.qv, -1, [&](int qu, int qv, int node, int) {       // NBLIC.c:628-637, :552-573
+                const uint32_t cu = S.cnt[qu][node], cv = S.cnt[qv][node];
+                const int u0 = int(cu & 0xFFFFu), u1 = int(cu >> 16);
+                const int v0 = int(cv & 0xFFFFu), v1 = int(cv >> 16);
+                const int prob = mix_prob(prob_one(u0, u1), prob_one(v0, v1), L.qw);
+                const uint32_t cut = lo + uint32_t((u64(hi - lo) * uint32_t(prob)) >> 12);
+                const int bin = sw.overrun ? 0 : int(window <= cut);     // past the end of the stream every symbol ends at once (a truncated stream must not spin)
+                if (bin) hi = cut; else lo = cut + 1;
+                while (((lo ^ hi) >> 24) == 0) { window = (window << 8) | sw.next(); lo <<= 8; hi = (hi << 8) | 0xFFu; }
+                Counter a{u0, u1};
+                counter_add(a, bin, kWeightOne - L.qw);
+                if (qu == qv) counter_add(a, bin, L.qw);                 // same counter takes both weights
+                S.cnt[qu][node] = uint32_t(a.c0) | (uint32_t(a.c1) << 16);
                 if (qu != qv) {
-                    Counter cv{v0, v1};
-                    counter_add(cv, bin, L.qw);
-                    S.c0[qv][node] = cv.c0; S.c1[qv][node] = cv.c1;
+                    Counter b{v0, v1};
+                    counter_add(b, bin, L.qw);
+                    S.cnt[qv][node] = uint32_t(b.c0) | (uint32_t(b.c1) << 16);
                 }
                 return bin;
-            };
-
-            int y;
-            if (!DEC) {
-                y = residual_to_symbol(pix(i, j), px, sign, near);
-                walk_symbol(k_step, L.qu, L.qv, y < kMapSyms ? int(S.rank_of[mk][y]) : y, step);
-            } else {
-                int z = walk_symbol(k_step, L.qu, L.qv, -1, step);
-                y = z < kMapSyms ? int(S.sym_at[mk][z]) : z;
-            }
-            if (y < kMapSyms) {                                                    // NBLIC.c:497-523
-                int z = S.rank_of[mk][y];
-                int c = S.count[mk][z] + 1;
-                int c_up = z > 0 ? S.count[mk][z - 1] : 0x7FFFFFFF;
-                int other = z > 0 ? int(S.sym_at[mk][z - 1]) : 0;
-                wave_sync();                                                       // every lane has read before any lane writes
+            });
+            const int y = z < kMapSyms ? int(S.sym_at[mk][z]) : z;
+            if (y < kMapSyms) {                                          // NBLIC.c:497-523 (z is y's rank)
+                const int c = S.count[mk][z] + 1;
+                const int c_up = z > 0 ? S.count[mk][z - 1] : 0x7FFFFFFF;
                 if (c_up < c) {
+                    const int other = S.sym_at[mk][z - 1];
                     S.count[mk][z] = c_up; S.count[mk][z - 1] = c;
                     S.sym_at[mk][z] = uint8_t(other); S.sym_at[mk][z - 1] = uint8_t(y);
                     S.rank_of[mk][y] = uint8_t(z - 1); S.rank_of[mk][other] = uint8_t(z);
@@ -279,65 +553,62 @@ __device__ void run_engine(const SerialArgs &a, Lds &S) {
                     S.count[mk][z] = c;
                 }
             }
-            int xr = symbol_to_pixel(y, px, sign, near);
-            if (lane0) img[size_t(i) * size_t(w) + size_t(j)] = uint8_t(xr);
+            const int xr = symbol_to_pixel(y, px, sign, np);
             err = clip_err(xr, px0);
             S.ctx[adr] = bias_update(v, err);
-            if (cached) S.rows[i % 3][j] = uint8_t(xr);
-            else __threadfence_block();
-            wave_sync();                                                           // the pixel is visible to every lane's next taps
-
-            if (n > 0) {                                                           // NBLIC.c:882-893
-                i64 xq = i64(xr) << kFb1;
-                i64 s_curr = abs64(p1 - xq);
-                i64 s_sum = (S.E[0] + F[0]) + s_curr * kDecayS / (kDecayS - 1);
+            if (CACHED) r0[j] = uint8_t(xr); else out[row_at + j] = uint8_t(xr);
+            if constexpr (N > 0) {
+                if (lane == 0) S.q.vn8[15] = int8_t(xr - kMid);
                 wave_sync();
-                lsq_update_wave(S, n, m, B, xr, s_curr, s_sum);
-                if (ok1 && ok2) bias = (abs64(p1 - xq) > abs64(p2 - xq)) ? b2 : b1;
+                lw.update(S.q, j, xr, p1_used);
+                wave_sync();
             }
         }
+        if (CACHED) {
+            wave_sync();
+            for (int c = lane; c < w; c += 64) out[row_at + c] = r0[c];
+        }
     }
-    if (!DEC) for (int k = 0; k < 4; k++) {                                        // NBLIC.c:576-586
-        if (rc.p < rc.end) { if (lane0) *rc.p = uint8_t(rc.lo >> 24); } else rc.overflow = true;
-        rc.p++; rc.lo <<= 8;
-    }
-    if (lane0) *a.len_out = rc.overflow ? -1L : long(rc.p - a.stream);
+    if (lane == 0) *J.status = sw.overrun ? -1 : 0;
 }
 
-__global__ void __launch_bounds__(64) k_serial_codec(SerialArgs a) {
-    __shared__ Lds S;
-    for (int k = int(threadIdx.x); k < kContexts; k += 64) S.ctx[k] = 0;
-    for (int k = int(threadIdx.x); k < kLevels * kTreeNodes; k += 64) { (&S.c0[0][0])[k] = kWeightOne; (&S.c1[0][0])[k] = kWeightOne; }
-    for (int k = int(threadIdx.x); k < 512 * kMapSyms; k += 64) {
-        int s = k % kMapSyms;
+template <int N>
+__global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restrict__ jobs, int dyn_bytes) {
+    __shared__ DecodeLds S;
+    extern __shared__ __align__(16) uint8_t rows[];
+    const SerialJob &J = jobs[blockIdx.x];
+    const int lane = int(threadIdx.x);
+    for (int k = lane; k < kContexts; k += 64) S.ctx[k] = 0;
+    for (int k = lane; k < kLevels * kTreeNodes; k += 64) (&S.cnt[0][0])[k] = uint32_t(kWeightOne) | (uint32_t(kWeightOne) << 16);
+    for (int k = lane; k < 512 * kMapSyms; k += 64) {
+        const int s = k % kMapSyms;
         (&S.count[0][0])[k] = 2 * (kMapSyms - 1 - s); (&S.rank_of[0][0])[k] = uint8_t(s); (&S.sym_at[0][0])[k] = uint8_t(s);
     }
-    __syncthreads();
-    if (a.decode) run_engine<true>(a, S); else run_engine<false>(a, S);
+    fill_qlut(S.qlut);
+    if (lane < 16) S.q.vn8[lane] = 0;
+    wave_sync();
+    const int rs = (J.w + 15) & ~15;
+    if (3 * rs <= dyn_bytes) decode_body<N, true>(S, rows, J, rs);
+    else decode_body<N, false>(S, rows, J, rs);
 }
 
-// ---- QNBLIC decoder (QNBLIC.c:493-555): one lane, context table + frequency tables in LDS ----
-struct QDecArgs {
-    uint8_t *img; const uint16_t *words; size_t n_words; size_t pos;
-    int h, w;
-    const uint32_t *freq, *start; const uint8_t *slot;
-    int *status;
-};
-
-__global__ void __launch_bounds__(64) k_serial_qdecode(QDecArgs a) {
+// ---- QNBLIC decoder (QNBLIC.c:493-555): context table + frequency tables in LDS, one image per wave ----
+__global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restrict__ jobs) {
     __shared__ int ctx[3072];
     __shared__ uint32_t freq[12 * 256], start[12 * 256];
-    for (int k = int(threadIdx.x); k < 3072; k += 64) { ctx[k] = 0; freq[k] = a.freq[k]; start[k] = a.start[k]; }
+    const SerialJob &J = jobs[blockIdx.x];
+    for (int k = int(threadIdx.x); k < 3072; k += 64) { ctx[k] = 0; freq[k] = J.q_freq[k]; start[k] = J.q_start[k]; }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    const int w = a.w;
-    uint8_t *img = a.img;
+    const int w = J.w;
+    uint8_t *img = J.recon;
+    const uint16_t *words = reinterpret_cast<const uint16_t *>(J.stream);
     auto pix = [&](int r, int c) { return int(img[size_t(r) * size_t(w) + size_t(c)]); };
-    size_t pos = a.pos;
-    bool bad = pos + 2 > a.n_words;
-    uint32_t x = bad ? 0u : ((uint32_t(a.words[pos]) << 16) | a.words[pos + 1]);
+    size_t pos = J.q_pos;
+    bool bad = pos + 2 > J.q_words;
+    uint32_t x = bad ? 0u : ((uint32_t(words[pos]) << 16) | words[pos + 1]);
     pos += 2;
-    for (int i = 0; i < a.h && !bad; i++) {
+    for (int i = 0; i < J.h && !bad; i++) {
         int err = 0;
         for (int j = 0; j < w; j++) {
             const Taps n = sample_taps_q(pix, w, i, j);
@@ -347,126 +618,97 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(QDecArgs a) {
             const int sign = (v >> 10) & 1;
             const int px = iclip(px0 + (v >> 11) + sign, 0, kMaxVal);
             const uint32_t low = x & 32767u;
-            const int y = a.slot[size_t(qd) * 32768 + low];
+            const int y = J.q_slot[size_t(qd) * 32768 + low];
             x = (x >> 15) * freq[qd * 256 + y] + low - start[qd * 256 + y];
-            if (x < 65536u) { if (pos >= a.n_words) { bad = true; break; } x = (x << 16) | a.words[pos++]; }
+            if (x < 65536u) { if (pos >= J.q_words) { bad = true; break; } x = (x << 16) | words[pos++]; }
             const int px_out = symbol_to_pixel(y, px, sign, 0);
             img[size_t(i) * size_t(w) + size_t(j)] = uint8_t(px_out);
             err = px_out - px0;
             ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
         }
     }
-    *a.status = bad ? -1 : 0;
+    *J.status = bad ? -1 : 0;
 }
 
-// ---- host side -------------------------------------------------------------------------------
-#define SE_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-    fprintf(stderr, "[nblic_amd] %s failed: %s\n", #call, hipGetErrorString(e_)); return -1; } } while (0)
-
-bool SerialEngine::init() {
-    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
-    return hipMalloc((void **)&d_len, sizeof(long)) == hipSuccess && hipMalloc((void **)&d_status, sizeof(int)) == hipSuccess;
+// ---- self-test: the double-carried divisions against 64-bit integers ------------------------------
+__global__ void k_selftest_div(const i64 *a, const i64 *b, const i64 *d, int n, uint32_t *bad) {
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n) return;
+    lsq::Guard g;
+    const double dd = double(d[t]);
+    const i64 want = mulw(a[t], b[t]) / d[t];
+    const double got = lsq::muldiv_trunc(double(a[t]), double(b[t]), dd, lsq::recip_short(dd), g);
+    const double rel = fabs(lsq::recip_short(dd) / lsq::kShort * dd - 1.0);            // the device reciprocal: seed + two Newton steps
+    if (!(rel < 1.0e-15)) atomicAdd(bad, 1u);
+    if (i64(got) != want) atomicAdd(bad, 1u);
+    const i64 v = a[t] >> 4;
+    if (i64(lsq::decay<5>(double(v))) != (v * 4 + 2) / 5 || i64(lsq::decay<3>(double(v))) != (v * 2 + 1) / 3) atomicAdd(bad, 1u);
 }
 
-void SerialEngine::destroy() {
-    hipFree(d_img); hipFree(d_stream); hipFree(d_stats); hipFree(d_len); hipFree(d_qtab); hipFree(d_status);
-    d_qtab = nullptr; d_status = nullptr;
-    if (stream) hipStreamDestroy(stream);
-    d_img = d_stream = nullptr; d_stats = nullptr; d_len = nullptr; stream = nullptr;
-}
-
-static long run_serial(SerialEngine &e, uint8_t *host_img, const uint8_t *host_in, size_t in_len, uint8_t *host_out,
-                       int h, int w, int near, int k_step, int effort, bool decode, int device) {
-    SE_OK(hipSetDevice(device));
-    size_t n = size_t(h) * size_t(w);
-    size_t cap = decode ? in_len + 8 : 2 * n + 4096;
-    int lsq_n = effort == 2 ? 6 : (effort == 3 ? 10 : 0);
-    size_t stats = lsq_n ? 2 * size_t(w) * size_t(1 + lsq_n + lsq_n * lsq_n) : 0;
-    if (n > e.img_cap) { hipFree(e.d_img); e.d_img = nullptr; SE_OK(hipMalloc((void **)&e.d_img, n)); e.img_cap = n; }
-    if (cap > e.stream_cap) { hipFree(e.d_stream); e.d_stream = nullptr; SE_OK(hipMalloc((void **)&e.d_stream, cap)); e.stream_cap = cap; }
-    if (stats > e.stats_cap) { hipFree(e.d_stats); e.d_stats = nullptr; SE_OK(hipMalloc((void **)&e.d_stats, stats * sizeof(int64_t))); e.stats_cap = stats; }
-    if (stats) SE_OK(hipMemsetAsync(e.d_stats, 0, stats * sizeof(int64_t), e.stream));        // NBLIC.c:789
-    if (decode) {
-        SE_OK(hipMemsetAsync(e.d_stream, 0, cap, e.stream));
-        SE_OK(hipMemcpyAsync(e.d_stream, host_in, in_len, hipMemcpyHostToDevice, e.stream));
-    } else {
-        SE_OK(hipMemcpyAsync(e.d_img, host_img, n, hipMemcpyHostToDevice, e.stream));
+int serial_selftest(hipStream_t s) {
+    constexpr int n = 1 << 16;
+    i64 *h = static_cast<i64 *>(malloc(3 * n * sizeof(i64))), *dv = nullptr;
+    uint32_t *d_bad = nullptr, bad = 1;
+    if (!h) return -1;
+    u64 x = 88172645463325252ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (int k = 0; k < n; k++) {
+        const int sa = 1 + int(rnd() % 44), sb = 1 + int(rnd() % 18), sd = 1 + int(rnd() % 30);       // |a b| < 2^62, |a b / d| < 2^48 is NOT guaranteed:
+        i64 a = i64(rnd() >> (64 - sa)), b = i64(rnd() >> (64 - sb)), d = i64(rnd() >> (64 - sd)) + 1; // keep the quotient inside the estimate's range
+        while (double(a) * double(b) / double(d) >= 6.0e13) d *= 2;
+        if (rnd() & 1) a = -a;
+        if (rnd() & 1) b = -b;
+        if (rnd() & 1) d = -d;
+        if (k < 64) { a = (k & 1) ? -(k / 2) : k / 2; b = 3 - (k % 7); d = (k % 5) - 2; if (d == 0) d = 1; }   // exact multiples, zeros, sign mixes
+        h[k] = a; h[n + k] = b; h[2 * n + k] = d;
     }
-    SerialArgs a{e.d_img, e.d_stream, cap, h, w, near, k_step, effort, decode ? 1 : 0, (long long *)e.d_stats, e.d_len};
-    hipLaunchKernelGGL(k_serial_codec, dim3(1), dim3(64), 0, e.stream, a);
-    long len = -1;
-    SE_OK(hipMemcpyAsync(&len, e.d_len, sizeof(long), hipMemcpyDeviceToHost, e.stream));
-    SE_OK(hipStreamSynchronize(e.stream));
-    if (len < 0) { fprintf(stderr, "[nblic_amd] serial engine: stream buffer exhausted\n"); return -1; }
-    SE_OK(hipMemcpy(host_img, e.d_img, n, hipMemcpyDeviceToHost));                           // reconstruction / decoded image
-    if (!decode) SE_OK(hipMemcpy(host_out + kHeaderBytes, e.d_stream + kHeaderBytes, size_t(len) - kHeaderBytes, hipMemcpyDeviceToHost));
-    return len;
+    if (hipMalloc((void **)&dv, 3 * n * sizeof(i64)) != hipSuccess || hipMalloc((void **)&d_bad, 4) != hipSuccess) { free(h); return -1; }
+    hipMemcpyAsync(dv, h, 3 * n * sizeof(i64), hipMemcpyHostToDevice, s);
+    hipMemsetAsync(d_bad, 0, 4, s);
+    hipLaunchKernelGGL(k_selftest_div, dim3(n / 256), dim3(256), 0, s, dv, dv + n, dv + 2 * n, n, d_bad);
+    hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    hipFree(dv); hipFree(d_bad); free(h);
+    return int(bad);
 }
 
-long SerialEngine::encode(uint8_t *out, uint8_t *img, int h, int w, int near, int k_step, int effort, int device) {
-    return run_serial(*this, img, nullptr, 0, out, h, w, near, k_step, effort, false, device);
+// ---- launchers ----------------------------------------------------------------------------------
+constexpr int kLdsBudget = 160 * 1024;
+
+template <class K>
+static bool launch_rows(K kernel, size_t static_lds, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
+    int max_w = 1;
+    for (int k = 0; k < n; k++) max_w = h_jobs[k].w > max_w ? h_jobs[k].w : max_w;
+    const int room = int(kLdsBudget - static_lds - 256) & ~15;
+    int dyn = 3 * ((max_w + 15) & ~15);
+    if (dyn > room) dyn = room;                  // wider images fall back to taps from memory (the kernel compares per job)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) return false;
+    hipLaunchKernelGGL(kernel, dim3(unsigned(n)), dim3(64), size_t(dyn), s, d_jobs, dyn);
+    return hipGetLastError() == hipSuccess;
 }
 
-// How many bytes of the caller's stream may be read.  The reference's decoder reads exactly the
-// bytes the encoder wrote and its ABI carries no length (NBLIC.h:72), so the copy to the device
-// is bounded by the end of the readable mapping that holds `p` and by the CLI's 2 B/px provision.
-static size_t readable_span(const uint8_t *p, size_t want) {
-    FILE *f = fopen("/proc/self/maps", "r");
-    if (!f) return want;
-    unsigned long lo, hi, addr = (unsigned long)p, end = 0;
-    char perms[8], line[512];
-    while (fgets(line, sizeof line, f)) {
-        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perms) != 3 || perms[0] != 'r') { if (end) break; continue; }
-        if (!end) { if (addr >= lo && addr < hi) end = hi; }
-        else if (lo == end) end = hi;                                   // contiguous readable mapping
-        else break;
+bool serial_model_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
+    if (n <= 0) return true;
+    switch (h_jobs[0].effort) {
+        case 1: return launch_rows(k_serial_model<0>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
+        case 2: return launch_rows(k_serial_model<6>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
+        default: return launch_rows(k_serial_model<10>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
     }
-    fclose(f);
-    if (!end) return want;
-    size_t avail = size_t(end - addr);
-    return avail < want ? avail : want;
 }
 
-int SerialEngine::decode(const uint8_t *in, uint8_t *img, int h, int w, int near, int k_step, int effort, int device) {
-    size_t want = 2 * size_t(h) * size_t(w) + 4096;
-    size_t len = readable_span(in, want);
-    long r = run_serial(*this, img, in, len, nullptr, h, w, near, k_step, effort, true, device);
-    return r < 0 ? -1 : 0;
+bool serial_decode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
+    if (n <= 0) return true;
+    switch (h_jobs[0].effort) {
+        case 1: return launch_rows(k_serial_decode<0>, sizeof(DecodeLds), d_jobs, h_jobs, n, s);
+        case 2: return launch_rows(k_serial_decode<6>, sizeof(DecodeLds), d_jobs, h_jobs, n, s);
+        default: return launch_rows(k_serial_decode<10>, sizeof(DecodeLds), d_jobs, h_jobs, n, s);
+    }
 }
 
-long q_decode_tables(const uint16_t *in, size_t n_words, int *h, int *w, uint32_t *freq, uint32_t *start, uint8_t *slot);
-
-int SerialEngine::qdecode(const uint16_t *in, uint8_t *img, int *h, int *w, long max_px, int device) {
-    SE_OK(hipSetDevice(device));
-    if (readable_span((const uint8_t *)in, 8) < 8) return -1;
-    if (in[0] != (uint16_t)('Q' | ('0' << 8)) || in[1] != (uint16_t)('.' | ('2' << 8))) return -1;      // QNBLIC.c:475-486
-    *h = in[2]; *w = in[3];
-    if (*h <= 0 || *w <= 0 || long(*h) * long(*w) > max_px) return -1;
-    const size_t n = size_t(*h) * size_t(*w);
-    const size_t n_words = readable_span((const uint8_t *)in, 2 * n + 16384) / 2;
-    const size_t tab_bytes = 2 * 12 * 256 * sizeof(uint32_t) + size_t(12) * 32768;
-    uint8_t *tabs = (uint8_t *)malloc(tab_bytes);
-    if (!tabs) return -1;
-    uint32_t *freq = (uint32_t *)tabs, *start = freq + 12 * 256;
-    uint8_t *slot = tabs + 2 * 12 * 256 * sizeof(uint32_t);
-    long pos = q_decode_tables(in, n_words, h, w, freq, start, slot);
-    if (pos < 0) { free(tabs); return -1; }
-    const size_t stream_bytes = n_words * 2;
-    if (n > img_cap) { hipFree(d_img); d_img = nullptr; SE_OK(hipMalloc((void **)&d_img, n)); img_cap = n; }
-    if (stream_bytes > stream_cap) { hipFree(d_stream); d_stream = nullptr; SE_OK(hipMalloc((void **)&d_stream, stream_bytes)); stream_cap = stream_bytes; }
-    if (!d_qtab) SE_OK(hipMalloc((void **)&d_qtab, tab_bytes));
-    SE_OK(hipMemcpyAsync(d_qtab, tabs, tab_bytes, hipMemcpyHostToDevice, stream));
-    SE_OK(hipMemcpyAsync(d_stream, in, stream_bytes, hipMemcpyHostToDevice, stream));
-    QDecArgs a{d_img, (const uint16_t *)d_stream, n_words, size_t(pos), *h, *w, (const uint32_t *)d_qtab,
-               (const uint32_t *)d_qtab + 12 * 256, d_qtab + 2 * 12 * 256 * sizeof(uint32_t), d_status};
-    hipLaunchKernelGGL(k_serial_qdecode, dim3(1), dim3(64), 0, stream, a);
-    int status = -1;
-    SE_OK(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
-    SE_OK(hipStreamSynchronize(stream));
-    free(tabs);
-    if (status != 0) return -1;
-    SE_OK(hipMemcpy(img, d_img, n, hipMemcpyDeviceToHost));
-    return 0;
+bool serial_qdecode_launch(const SerialJob *d_jobs, int n, hipStream_t s) {
+    if (n <= 0) return true;
+    hipLaunchKernelGGL(k_serial_qdecode, dim3(unsigned(n)), dim3(64), 0, s, d_jobs);
+    return hipGetLastError() == hipSuccess;
 }
 
 }  // namespace nblic

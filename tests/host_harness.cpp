@@ -65,7 +65,7 @@ bool solve_f64(int n, double M[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, lsq::
         const double d = M[c][k];
         diag[c] = d;
         if (d == 0.0) return false;
-        const double rd = 1.0 / d;
+        const double rd = lsq::recip_short(d);
         for (int r = 0; r < n; r++) {
             if (pos[r] <= k) continue;
             const double l = M[r][k];
@@ -80,7 +80,7 @@ bool solve_f64(int n, double M[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, lsq::
         const int c = at[k];
         const double d = diag[c];
         if (d == 0.0) return false;
-        const double rd = 1.0 / d, bk = M[c][n];
+        const double rd = lsq::recip_short(d), bk = M[c][n];
         for (int r = 0; r < n; r++) {
             if (pos[r] >= k) continue;
             M[r][n] -= lsq::muldiv_trunc(bk, M[r][k], d, rd, g);
@@ -179,7 +179,7 @@ extern "C" long hh_model_encode(const uint8_t *img_in, uint8_t *recon, int h, in
                 const i64 xq = i64(xr) << lsq::kFb1;
                 const double s_curr = double(abs64(p1 - xq));
                 const double s_sum = (E[0] + Fj[0]) + floor(s_curr * double(lsq::kDecayS) / double(lsq::kDecayS - 1));
-                const double s = lsq::sample_weight(s_sum), rs = 1.0 / s;
+                const double s = lsq::sample_weight(s_sum), rs = lsq::recip_short(s);
                 const int xc = xr - kMid;
                 for (int k = 0; k < m; k++) {
                     double sample;
@@ -196,4 +196,38 @@ extern "C" long hh_model_encode(const uint8_t *img_in, uint8_t *recon, int h, in
     }
     if (fallbacks) *fallbacks = n_fallback;
     return n_bins;
+}
+
+// Exhaustive comparison of the divide-free helpers the serial kernels use (model.h NearParams,
+// level_shift_table / walk_symbol_t) with the plain formulations.  Returns the number of mismatches.
+extern "C" long hh_check_divide_free(void) {
+    long bad = 0;
+    for (int near = 0; near <= kMaxNear; near++) {
+        const NearParams np = near_params(near);
+        for (int num = 0; num < 2048; num++) bad += div_width(num, np) != num / (2 * near + 1);
+        for (int px = 0; px < 256; px++)
+            for (int sign = 0; sign < 2; sign++) {
+                for (int x = 0; x < 256; x++) bad += residual_to_symbol(x, px, sign, np) != residual_to_symbol(x, px, sign, near);
+                for (int y = 0; y < 300; y++) bad += symbol_to_pixel(y, px, sign, np) != symbol_to_pixel(y, px, sign, near);
+            }
+        const int k_step = k_step_for_near(near);
+        const uint64_t ktab = level_shift_table(k_step);
+        for (int qu = 0; qu < kLevels; qu++)
+            for (int dq = -1; dq <= 1; dq++) {
+                const int qv = qu + dq;
+                if (qv < 0 || qv >= kLevels) continue;
+                for (int z = 0; z < 256; z++) {
+                    long sig_a = 0, sig_b = 0;
+                    auto rec = [](long &sig) { return [&sig](int a, int b, int node, int bin) { sig = sig * 1000003 + ((a * 16 + b) * 256 + node) * 2 + bin; return bin; }; };
+                    const int za = walk_symbol(k_step, qu, qv, z, rec(sig_a));
+                    const int zb = walk_symbol_t(k_step, ktab, qu, qv, z, rec(sig_b));
+                    bad += za != zb || sig_a != sig_b;
+                }
+            }
+    }
+    for (int d = 0; d < 2000; d++) {                              // the activity table of the serial kernels clips at 200
+        const Level a = quantise(d), b = quantise(d < 200 ? d : 200);
+        bad += a.qu != b.qu || a.qv != b.qv || a.qw != b.qw;
+    }
+    return bad;
 }

@@ -60,3 +60,24 @@ def test_pack_roundtrip():
     gather = importlib.import_module("nblic-image-compression_amd.gather")
     payload, lens = gather.pack([b"abc", b"", b"defgh"])
     assert payload.tobytes() == b"abcdefgh" and lens.tolist() == [3, 0, 5]
+
+
+def test_bench_gpus_flag_launches_ranks():
+    """`python bench.py --gpus 2` started directly must itself become two ranks (one per GPU): here with
+    --launch-check, which joins a gloo group and touches no GPU; rank 0's line reports what it saw."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 2, "ranks_seen": 2, "local_rank": 0}
+
+
+def test_bench_refuses_mislabelled_world():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -331,3 +331,92 @@ def test_overlapping_batches_begin_end(pkg, oracle):
     for b, imgs in enumerate(batches):
         assert results[b] == [oracle.encode(img, 0, 1)[0] for img in imgs], b
     assert again == results[0][:3]
+
+
+# ---- serial modes: model stage one wave per image + parallel entropy stages; batch decoders ------
+def test_serial_arithmetic_selftest(gpu_ctx):
+    """The double-carried truncating divisions of the least-squares predictor (csrc/lsq_f64.h) against
+    64-bit integer division, on the device."""
+    assert gpu_ctx.serial_selftest() == 0
+
+
+SERIAL_1024 = ["syn1s1_1024x1024_n0_e2", "syn1s1_1024x1024_n0_e3", "syn1s1_1024x1024_n2_e1", "syn1s1_1024x1024_n2_e2", "syn1s1_1024x1024_n9_e1"]
+SERIAL_WIDE = ["syn1s1_64x16384_n0_e3", "syn1s1_24x16384_n2_e2", "syn1s1_16x16385_n0_e3", "syn1s1_3x20000_n0_e1", "syn1s1_3x20000_n2_e2",
+               "syn1s1_3x20000_n1_e3", "syn1s1_8x16384_n3_e1", "syn1s1_6x16385_n2_e1", "syn1s1_512x512_n0_e2", "syn1s1_512x512_n0_e3",
+               "syn1s1_512x512_n2_e2", "syn1s1_512x512_n1_e3"]
+
+
+def _key_case(key):
+    from oracle.oracle import syn1
+    name, dims, n, e = key.split("_")
+    h, w = map(int, dims.split("x"))
+    return syn1(h, w, int(name[5:])), int(n[1:]), int(e[1:])
+
+
+def test_serial_goldens_one_batch(pkg, golden):
+    """SURVEY App. B's reference-held goldens at 1024^2 (n0e2 e9125b0c, n0e3 6c05e3cc, n2e1 05c22e7e, n2e2
+    0323001d, n9e1 9c37cab5) plus wide strips around the 16384-pixel row (LDS row cache, 29 MB of
+    statistics) and 512^2 frames: all in ONE batch, every image a wave of its own; then the streams are
+    decoded in one batch and must give the reference's reconstruction."""
+    manifest, _ = golden
+    keys = SERIAL_1024 + SERIAL_WIDE
+    cases = [_key_case(k) for k in keys]
+    ctx = pkg.Context(device=0, n_slots=24, n_coders=4, n_groups=2, n_host_buffers=48)
+    try:
+        streams, recs = ctx.encode_modes([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+        dec = ctx.decode_batch(streams)
+    finally:
+        ctx.close()
+    assert manifest["serial"]["syn1s1_1024x1024_n0_e2"]["sha256"].startswith("e9125b0c10fa1b51")
+    assert manifest["serial"]["syn1s1_1024x1024_n0_e3"]["sha256"].startswith("6c05e3cc0745eb12")
+    for key, s, rec, d, case in zip(keys, streams, recs, dec, cases):
+        m = manifest["serial"][key]
+        assert (len(s), sha(s)) == (m["len"], m["sha256"]), key
+        assert sha(rec.tobytes()) == m["recon_sha256"], key
+        assert d is not None and np.array_equal(d[0], rec) and (d[1], d[2]) == (case[1], case[2]), key
+
+
+def test_serial_batch_many_images_in_flight(pkg, oracle):
+    """160 images of every mode in one call (>= 128 in flight: 2 groups x 80 slots), mixed with -n0 -e1
+    images that take the staged pipeline; every stream and reconstruction against the oracle; then one
+    batch decode (NBLIC and QNBLIC streams mixed) against the oracle's decoders."""
+    rng = np.random.default_rng(5)
+    modes = [(0, 1), (0, 2), (0, 3), (1, 1), (2, 1), (2, 2), (9, 1), (3, 3), (5, 2), (1, 3)]
+    imgs, nears, efforts = [], [], []
+    for k in range(160):
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 90))
+        imgs.append(inputs.make(inputs.CONTENTS[k % len(inputs.CONTENTS)], h, w) if k % 3 else inputs.syn1(h, w, seed=k + 1))
+        nears.append(modes[k % len(modes)][0]); efforts.append(modes[k % len(modes)][1])
+    ctx = pkg.Context(device=0, n_slots=160, n_coders=4, n_groups=2, n_host_buffers=200)
+    try:
+        streams, recs = ctx.encode_modes(imgs, nears, efforts)
+        q = ctx.qencode_batch(imgs[:8])
+        dec = ctx.decode_batch(streams + q + [b"NBLIC0.3" + bytes(30), b"junk"])
+    finally:
+        ctx.close()
+    for k, (img, s, rec) in enumerate(zip(imgs, streams, recs)):
+        ws, wrec, *_ = oracle.encode(img, nears[k], efforts[k])
+        assert s == ws and np.array_equal(rec, wrec), (k, img.shape, nears[k], efforts[k])
+        assert dec[k] is not None and np.array_equal(dec[k][0], wrec) and dec[k][1:] == (nears[k], efforts[k]), k
+    for k in range(8):
+        assert dec[160 + k] is not None and np.array_equal(dec[160 + k][0], imgs[k]), k
+    assert dec[-2] is None and dec[-1] is None
+
+
+def test_dropin_limit_is_opt_in(pkg):
+    """The drop-in symbols refuse > 100,000,000 pixels (NBLIC.h:31) until the limit is raised for the
+    context behind them (nblic_amd_set_max_pixels(NULL, ...)); a 3 x 40,000,000-pixel-wide frame cannot exist
+    (65535 columns at most), so the check runs on the limit logic alone."""
+    import ctypes as C
+    lib = pkg.load_library()
+    u8p = C.POINTER(C.c_uint8)
+    img = np.zeros((2, 3), np.uint8)
+    out = np.empty(4096, np.uint8)
+    n, e = C.c_int(0), C.c_int(2)
+    assert lib.NBLICcompress(0, out.ctypes.data_as(u8p), img.ctypes.data_as(u8p), 10001, 10000, C.byref(n), C.byref(e)) == -1
+    pkg.set_default_max_pixels(5)
+    try:
+        assert lib.NBLICcompress(0, out.ctypes.data_as(u8p), img.ctypes.data_as(u8p), 2, 3, C.byref(n), C.byref(e)) == -1
+    finally:
+        pkg.set_default_max_pixels(0)
+    assert lib.NBLICcompress(0, out.ctypes.data_as(u8p), img.ctypes.data_as(u8p), 2, 3, C.byref(n), C.byref(e)) > 0
