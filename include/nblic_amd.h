@@ -184,6 +184,27 @@ int nblic_amd_range_code_multi(const uint16_t *const *coded, const size_t *n, in
 int nblic_amd_range_code_chunked(const uint16_t *const *coded, const size_t *n, int count, unsigned char *const *outs,
                                  const size_t *caps, size_t *lens, size_t chunk);
 
+/* ---- 3. front end: image files and the reference tool's command line (host only) ----------------- */
+
+/* The reference tool's main() (src/NBLIC_main.c:139-254) on this library: same switch grammar (groups
+ * such as "-cn2e2V"), same PGM-then-BMP probing of the input (:168-169), -n0 -e0 -> QNBLIC with the word
+ * count doubled (:182-188), QNBLIC-then-NBLIC decoding (:223-226), ".bmp" suffix -> BMP output (:233).
+ * Returns 0, or -1 after printing an "***Error" line.  The `nblic_codec_amd` executable is this call.  */
+int nblic_amd_cli_main(int argc, char **argv);
+
+/* The parsed command line (tests of the grammar): fields[0..7] = decompress, near, effort, verbose,
+ * multithread, large-image opt-in (-L), device (-g<N>, -1 = unset), have_src | have_dst << 1.            */
+void nblic_amd_cli_parse(int argc, char **argv, int *fields, char *src, char *dst, size_t cap);
+
+/* Reads an 8-bit gray image the way the reference's front end does (src/FileIO.c:81-131 binary PGM, then
+ * :170-225 8-bit BMP: bottom-up rows, 4-byte row padding, pixel = palette index).  Writes h*w bytes (row
+ * major, top-down) to px.  Returns 1 = PGM, 2 = BMP, 0 = neither, -1 = cap too small (*h, *w still set). */
+int nblic_amd_read_gray(const char *path, unsigned char *px, size_t cap, int *h, int *w);
+
+/* Writes "P5\n<w> <h>\n255\n" + pixels (src/FileIO.c:141-159), or with as_bmp != 0 the 1078-byte header
+ * (identity gray palette) + bottom-up padded rows (src/FileIO.c:229-287).  Returns 0 / -1.               */
+int nblic_amd_write_gray(const char *path, const unsigned char *px, int h, int w, int as_bmp);
+
 /* Device self-test of the serial kernels' arithmetic: the double-carried truncating divisions of the
  * least-squares predictor against 64-bit integer division on 65536 operand triples.  0 = pass.   */
 int nblic_amd_serial_selftest(nblic_amd_ctx *ctx);

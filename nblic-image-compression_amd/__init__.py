@@ -38,6 +38,7 @@ EXPORTS = (
     "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_encode_batch_begin", "nblic_amd_encode_batch_end", "nblic_amd_qencode_batch", "nblic_amd_set_max_pixels",
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
     "nblic_amd_encode_batch_modes", "nblic_amd_decode_batch", "nblic_amd_serial_selftest",
+    "nblic_amd_cli_main", "nblic_amd_cli_parse", "nblic_amd_read_gray", "nblic_amd_write_gray",
     "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_range_code_chunked", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
 )
 
@@ -99,6 +100,14 @@ def load_library() -> C.CDLL:
                                            C.POINTER(C.c_size_t), ip, ip, ip, ip, ip]
     lib.nblic_amd_serial_selftest.restype = C.c_int
     lib.nblic_amd_serial_selftest.argtypes = [C.c_void_p]
+    lib.nblic_amd_cli_main.restype = C.c_int
+    lib.nblic_amd_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    lib.nblic_amd_cli_parse.restype = None
+    lib.nblic_amd_cli_parse.argtypes = [C.c_int, C.POINTER(C.c_char_p), ip, C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.nblic_amd_read_gray.restype = C.c_int
+    lib.nblic_amd_read_gray.argtypes = [C.c_char_p, _u8p, C.c_size_t, ip, ip]
+    lib.nblic_amd_write_gray.restype = C.c_int
+    lib.nblic_amd_write_gray.argtypes = [C.c_char_p, _u8p, C.c_int, C.c_int, C.c_int]
     lib.nblic_amd_set_max_pixels.restype = None
     lib.nblic_amd_set_max_pixels.argtypes = [C.c_void_p, C.c_long]
     lib.nblic_amd_enable_timing.restype = None
@@ -173,6 +182,47 @@ def decompress(stream: bytes) -> Optional[Tuple[np.ndarray, int, int]]:
 def set_default_max_pixels(n: int) -> None:
     """Opt-in pixel limit of the context behind the drop-in operators (``nblic_amd_set_max_pixels(NULL, n)``)."""
     load_library().nblic_amd_set_max_pixels(None, n)
+
+
+CLI_PATH = os.path.join(_HERE, "nblic_codec_amd")
+
+
+def cli(args: Sequence[str]) -> int:
+    """Run the reference tool's command line in-process (``nblic_amd_cli_main``); args exclude argv[0]."""
+    lib = load_library()
+    argv = [b"nblic_codec_amd"] + [a.encode() for a in args]
+    arr = (C.c_char_p * len(argv))(*argv)
+    return int(lib.nblic_amd_cli_main(len(argv), arr))
+
+
+def cli_parse(args: Sequence[str]) -> dict:
+    """The switch grammar alone (``nblic_amd_cli_parse``)."""
+    lib = load_library()
+    argv = [b"nblic_codec_amd"] + [a.encode() for a in args]
+    arr = (C.c_char_p * len(argv))(*argv)
+    f = (C.c_int * 8)()
+    src, dst = C.create_string_buffer(4096), C.create_string_buffer(4096)
+    lib.nblic_amd_cli_parse(len(argv), arr, f, src, dst, 4096)
+    return {"decompress": f[0], "near": f[1], "effort": f[2], "verbose": f[3], "multithread": f[4], "large": f[5], "device": f[6],
+            "src": src.value.decode() if f[7] & 1 else None, "dst": dst.value.decode() if f[7] & 2 else None}
+
+
+def read_gray(path: str) -> Optional[Tuple[np.ndarray, str]]:
+    """An 8-bit gray PGM or BMP as the reference's front end reads it.  Returns (image, "PGM" | "BMP") or None."""
+    lib = load_library()
+    h, w = C.c_int(), C.c_int()
+    probe = np.empty(1, np.uint8)
+    kind = lib.nblic_amd_read_gray(path.encode(), probe.ctypes.data_as(_u8p), 0, C.byref(h), C.byref(w))
+    if kind == 0:
+        return None
+    img = np.empty((h.value, w.value), np.uint8)
+    kind = lib.nblic_amd_read_gray(path.encode(), img.ctypes.data_as(_u8p), img.size, C.byref(h), C.byref(w))
+    return (img, "PGM" if kind == 1 else "BMP") if kind > 0 else None
+
+
+def write_gray(path: str, img: np.ndarray, as_bmp: bool) -> bool:
+    img = np.ascontiguousarray(img, np.uint8)
+    return load_library().nblic_amd_write_gray(path.encode(), img.ctypes.data_as(_u8p), img.shape[0], img.shape[1], int(as_bmp)) == 0
 
 
 def syn1(h: int, w: int, seed: int = 1) -> np.ndarray:

@@ -23,6 +23,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define LSQ_HD __host__ __device__ __forceinline__
@@ -37,17 +38,32 @@ constexpr int kMaxN = 10;                               // N_LIST, NBLIC.c:88: e
 constexpr int kFb1 = 12, kFb2 = 2, kFb3 = 10;           // fixed-point positions, NBLIC.c:66-68
 constexpr int kDecayS = 3, kDecayV = 5;                 // ALPHA, BETA analogues: decay (ab-1)/ab of the weight / value channels
 constexpr int kBiasInit = 8, kBiasMax = 4096, kBiasCoef = 21;
-constexpr double kProductLimit = 4611686018427387904.0; // 2^62: beyond it the reference's int64 product may wrap
-constexpr double kEntryLimit = 17592186044416.0;        // 2^44: entries stay exact and the pivot key (|v| * 256 + tag) fits 53 bits
-constexpr double kQuotientLimit = 70368744177664.0;     // 2^46: an estimate this large may be off by more than one
 
 LSQ_HD int order_of(int effort) { return effort == 2 ? 6 : (effort == 3 ? kMaxN : 0); }
 LSQ_HD int vec_len(int n) { return 1 + n + n * n; }     // [s | b(n) | A(n x n)], NBLIC.c:213-215
 
-// sticky record of the magnitudes one solve has seen; ok() false => redo with integers
+// Sticky record of the magnitudes one solve has seen, kept as the HIGH WORDS of the largest |values|
+// (sign cleared): for power-of-two limits "high word below the limit's high word" is exactly
+// "|v| below the limit", it costs two 32-bit integer operations instead of a 64-bit float maximum, and an
+// infinity or a NaN reads as over the limit.  ok() false => redo the pixel with integers.
+LSQ_HD uint32_t magnitude_word(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return uint32_t(__double2hiint(v)) & 0x7FFFFFFFu;
+#else
+    uint64_t b;
+    memcpy(&b, &v, sizeof b);
+    return uint32_t(b >> 32) & 0x7FFFFFFFu;
+#endif
+}
+constexpr uint32_t pow2_word(int k) { return uint32_t(1023 + k) << 20; }
 struct Guard {
-    double product = 0.0, entry = 0.0, quotient = 0.0;
-    LSQ_HD bool ok() const { return product < kProductLimit && entry < kEntryLimit && quotient < kQuotientLimit; }
+    uint32_t product = 0, entry = 0, quotient = 0;
+    LSQ_HD void see_product(double v) { const uint32_t m = magnitude_word(v); product = m > product ? m : product; }
+    LSQ_HD void see_entry(double v) { const uint32_t m = magnitude_word(v); entry = m > entry ? m : entry; }
+    LSQ_HD void see_quotient(double v) { const uint32_t m = magnitude_word(v); quotient = m > quotient ? m : quotient; }
+    // 2^62: beyond it the reference's int64 product may wrap; 2^44: entries stay exact and the pivot key (|v| * 256 + tag)
+    // fits 53 bits; 2^46: an estimate this large may be off by more than one
+    LSQ_HD bool ok() const { return product < pow2_word(62) && entry < pow2_word(44) && quotient < pow2_word(46); }
 };
 
 // ---- truncating division by estimate + exact remainder -------------------------------------------
@@ -83,7 +99,7 @@ LSQ_HD double unit_with_sign_of(double a, double b) {
 LSQ_HD double div_trunc(double n, double d, double rs) {
     const double q0 = trunc(n * rs);
     const double r = fma(-q0, d, n);                     // exact; same sign as n, |r| < 2|d|
-    return fabs(r) >= fabs(d) ? q0 + unit_with_sign_of(n, d) : q0;
+    return q0 + (fabs(r) >= fabs(d) ? unit_with_sign_of(n, d) : 0.0);
 }
 
 // trunc(a * b / d) with the product carried exactly as p + e (|a b| may exceed 2^53).
@@ -92,8 +108,8 @@ LSQ_HD double muldiv_trunc(double a, double b, double d, double rs, Guard &g) {
     const double e = fma(a, b, -p);                      // a*b == p + e exactly
     const double q0 = trunc(p * rs);
     const double r = fma(-q0, d, p) + e;                 // exact remainder of the estimate
-    g.product = fmax(g.product, fabs(p));
-    return fabs(r) >= fabs(d) ? q0 + unit_with_sign_of(p, d) : q0;
+    g.see_product(p);
+    return q0 + (fabs(r) >= fabs(d) ? unit_with_sign_of(p, d) : 0.0);
 }
 
 // (v * (ab-1) + ab/2) / ab, truncating (NBLIC.c:199, :273-279); |v| < 2^44
@@ -123,8 +139,8 @@ constexpr double kScaleA = 262144.0;                     // 1 << (4 + FB2 + FB1)
 LSQ_HD double term(double b, int vn, double d, Guard &g) {
     const double n = fma(b, double(vn * (1 << kFb2)), floor(d * 0.5));
     const double rs = recip_short(d);
-    g.quotient = fmax(g.quotient, fabs(n * rs));
-    g.entry = fmax(g.entry, fabs(b));
+    g.see_quotient(n * rs);
+    g.see_entry(b);
     return div_trunc(n, d, rs);
 }
 

@@ -46,9 +46,15 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 constexpr int kRor1 = 0x121, kRor2 = 0x122, kRor4 = 0x124, kRor8 = 0x128;   // rotate right inside each 16-lane row
+// one v_max_f64 (the library fmax wraps each operand in a canonicalising maximum of its own; the keys are never NaN)
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ double row_max(double v) {
-    v = fmax(v, dpp_f64<kRor1>(v)); v = fmax(v, dpp_f64<kRor2>(v));
-    v = fmax(v, dpp_f64<kRor4>(v)); v = fmax(v, dpp_f64<kRor8>(v));
+    v = max_f64(v, dpp_f64<kRor1>(v)); v = max_f64(v, dpp_f64<kRor2>(v));
+    v = max_f64(v, dpp_f64<kRor4>(v)); v = max_f64(v, dpp_f64<kRor8>(v));
     return v;
 }
 __device__ __forceinline__ double row_sum(double v) {
@@ -192,7 +198,7 @@ __device__ __forceinline__ double lsq_solve_rows(double (&M)[N + 1], const int r
 #pragma unroll
         for (int j = k + 1; j <= N; j++) {
             M[j] -= lsq::muldiv_trunc(fetch_f64(M[j], src), l, d, rs, g);
-            g.entry = fmax(g.entry, fabs(M[j]));
+            g.see_entry(M[j]);
         }
     }
     at[N - 1] = N * (N - 1) / 2 - at_sum;
@@ -204,7 +210,7 @@ __device__ __forceinline__ double lsq_solve_rows(double (&M)[N + 1], const int r
         ok &= int(d != 0.0);
         const double l = (live & (pos < k)) ? M[k] : 0.0;
         M[N] -= lsq::muldiv_trunc(bk, l, d, lsq::recip_short(d), g);
-        g.entry = fmax(g.entry, fabs(M[N]));
+        g.see_entry(M[N]);
     }
     const int v = vn8[live ? pos : 14];
     const double t = lsq::term(live ? M[N] : 0.0, v, diag, g);            // NBLIC.c:233-236
@@ -360,6 +366,50 @@ __device__ __forceinline__ void store_regressors(int8_t *vn8, const Taps &t) {
     w[2] = b(t.q) | (b(t.g) << 8);
 }
 
+// ---- causal taps from the LDS row ring, as a sliding window --------------------------------------
+// The twelve RAW neighbours (columns clamped into the row, so every address is valid; rows above the
+// image read whatever the ring holds) live in registers and shift by one column per pixel; only the two
+// right-most ones (rows i-1 and i-2, column j+2) are new, and they are requested one pixel AHEAD, so a
+// pixel never waits for its taps.  The reference's fall-back chain (NBLIC.c:287-304) is applied to the raw
+// values with selects.
+struct TapWindow {
+    int A, E, B, C, D, Q, T, F, G, H, R, S;          // raw: a e / b c d q t / f g h r s
+    int Tn, Rn;                                      // column j+3 of rows i-1 / i-2, in flight
+    __device__ __forceinline__ void row_start(const uint8_t *r0, const uint8_t *r1, const uint8_t *r2, int w) {
+        auto cl = [w](int c) { return c < 0 ? 0 : (c >= w ? w - 1 : c); };
+        A = r0[0]; E = r0[0];
+        B = r1[0]; C = r1[0]; D = r1[cl(1)]; Q = r1[0]; T = r1[cl(2)];
+        F = r2[0]; H = r2[0]; G = r2[cl(1)]; S = r2[0]; R = r2[cl(2)];
+        Tn = r1[cl(3)]; Rn = r2[cl(3)];
+    }
+    // after pixel j has been reconstructed as xr: the window of pixel j+1; requests column j+4
+    __device__ __forceinline__ void advance(const uint8_t *r1, const uint8_t *r2, int w, int j, int xr) {
+        E = j >= 1 ? A : xr; A = xr;                                   // at j == 0 the raw A was never a coded pixel
+        Q = C; C = B; B = D; D = T; T = Tn;
+        S = H; H = F; F = G; G = R; R = Rn;
+        const int c = j + 4 < w ? j + 4 : w - 1;
+        Tn = r1[c]; Rn = r2[c];
+    }
+    __device__ __forceinline__ Taps taps(int w, int i, int j) const {
+        const bool up1 = i >= 1, up2 = i >= 2, l1 = j >= 1, l2 = j >= 2, r1_ = j + 1 < w, r2_ = j + 2 < w;
+        Taps n;
+        int a = l1 ? A : kMid, b = up1 ? B : kMid;
+        if (!up1) b = a; else if (!l1) a = b;
+        n.a = a; n.b = b;
+        n.e = l2 ? E : a;
+        n.c = (up1 && l1) ? C : b;
+        n.d = (up1 && r1_) ? D : b;
+        n.f = up2 ? F : b;
+        n.g = (up2 && r1_) ? G : n.f;
+        n.h = (up2 && l1) ? H : n.f;
+        n.q = (up1 && l2) ? Q : n.c;
+        n.r = (up2 && r2_) ? R : n.g;
+        n.s = (up2 && l2) ? S : n.h;
+        n.t = (up1 && r2_) ? T : n.d;
+        return n;
+    }
+};
+
 // ---- encoder: the serial model stage (prediction, context bias, quantisation) ------------------
 // CACHED: the three rows the taps can touch live in LDS (a ring, row r at r % 3), so a pixel's twelve
 // taps are twelve LDS reads issued together; otherwise (rows wider than the LDS left over) they come
@@ -389,9 +439,13 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
         };
         if constexpr (N > 0) lw.row_begin(S.q);
         int err = 0;
+        TapWindow tw;
+        int x_next = 0;
+        if (CACHED) { tw.row_start(r0, r1, r2, w); x_next = r0[0]; }
         for (int j = 0; j < w; j++) {
-            const Taps t = sample_taps(pix, w, i, j);
-            const int x = CACHED ? int(r0[j]) : int(img[row_at + j]);
+            const Taps t = CACHED ? tw.taps(w, i, j) : sample_taps(pix, w, i, j);
+            const int x = CACHED ? x_next : int(img[row_at + j]);
+            if (CACHED) x_next = r0[j + 1 < w ? j + 1 : j];                // the next original pixel: requested a pixel ahead
             int px0;
             i64 p1_used = 0;
             if constexpr (N > 0) {
@@ -412,7 +466,7 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
             const int xr = symbol_to_pixel(y, px, sign, np);
             err = clip_err(xr, px0);
             S.ctx[adr] = bias_update(v, err);
-            if (CACHED) r0[j] = uint8_t(xr); else recon[row_at + j] = uint8_t(xr);
+            if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else recon[row_at + j] = uint8_t(xr);
             S.rec_ring[j & 63] = pack_s1(px0, adr, L);
             S.pxs_ring[j & 63] = uint16_t(px | (sign << 8));
             if ((j & 63) == 63 || j == w - 1) {                          // a lane per record: coalesced stores
@@ -501,8 +555,10 @@ __device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const S
         if constexpr (N > 0) lw.row_begin(S.q);
         int err = 0;
         const size_t row_at = size_t(i) * size_t(w);
+        TapWindow tw;
+        if (CACHED) tw.row_start(r0, r1, r2, w);
         for (int j = 0; j < w; j++) {
-            const Taps t = sample_taps(pix, w, i, j);
+            const Taps t = CACHED ? tw.taps(w, i, j) : sample_taps(pix, w, i, j);
             int px0;
             i64 p1_used = 0;
             if constexpr (N > 0) {
@@ -556,7 +612,7 @@ __device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const S
             const int xr = symbol_to_pixel(y, px, sign, np);
             err = clip_err(xr, px0);
             S.ctx[adr] = bias_update(v, err);
-            if (CACHED) r0[j] = uint8_t(xr); else out[row_at + j] = uint8_t(xr);
+            if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else out[row_at + j] = uint8_t(xr);
             if constexpr (N > 0) {
                 if (lane == 0) S.q.vn8[15] = int8_t(xr - kMid);
                 wave_sync();

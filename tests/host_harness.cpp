@@ -52,7 +52,7 @@ bool solve_int(int n, const double Md[lsq::kMaxN][lsq::kMaxN + 1], const int *vn
 bool solve_f64(int n, double M[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, lsq::Guard &g, double *px) {
     int pos[lsq::kMaxN], at[lsq::kMaxN];
     double diag[lsq::kMaxN];
-    for (int i = 0; i < n; i++) { pos[i] = i; at[i] = i; for (int j = 0; j <= n; j++) g.entry = fmax(g.entry, fabs(M[i][j])); }
+    for (int i = 0; i < n; i++) { pos[i] = i; at[i] = i; for (int j = 0; j <= n; j++) g.see_entry(M[i][j]); }
     for (int k = 0; k + 1 < n; k++) {
         int c = -1; double best = -1.0;
         for (int r = 0; r < n; r++) {
@@ -71,7 +71,7 @@ bool solve_f64(int n, double M[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, lsq::
             const double l = M[r][k];
             for (int j = k + 1; j <= n; j++) {
                 M[r][j] -= lsq::muldiv_trunc(M[c][j], l, d, rd, g);
-                g.entry = fmax(g.entry, fabs(M[r][j]));
+                g.see_entry(M[r][j]);
             }
         }
     }
@@ -84,7 +84,7 @@ bool solve_f64(int n, double M[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, lsq::
         for (int r = 0; r < n; r++) {
             if (pos[r] >= k) continue;
             M[r][n] -= lsq::muldiv_trunc(bk, M[r][k], d, rd, g);
-            g.entry = fmax(g.entry, fabs(M[r][n]));
+            g.see_entry(M[r][n]);
         }
     }
     double p = double(kMid << lsq::kFb1);
