@@ -156,7 +156,11 @@ static int cli_run(const CliOptions &o) {
 
 extern "C" {
 
-int nblic_amd_cli_main(int argc, char **argv) { return nblic::cli_run(nblic::parse_command(argc, argv)); }
+int nblic_amd_cli_main(int argc, char **argv) {
+    const int rc = nblic::cli_run(nblic::parse_command(argc, argv));
+    fflush(stdout);                                              // callers that embed this (tests) read the text right away
+    return rc;
+}
 
 // the parsed command line, for tests of the switch grammar: fields[0..7] = decompress, near, effort, verbose,
 // multithread, large, device, (have_src | have_dst << 1); the two names are copied into src / dst (cap bytes each)

@@ -50,6 +50,18 @@ __device__ __forceinline__ NB_GLOBAL T *gptr(T *p) {
 __device__ __forceinline__ int lane_id() { return int(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
 
+// Workgroups are dealt to the 8 XCDs round-robin (blocks b and b + 8 share an XCD, each XCD has an L2 of
+// its own), so with the plain blockIdx -> work mapping every L2 sees every 8th piece of a raster-ordered
+// pass: a gather through key-sorted positions then pulls each 64-byte line of a chain into all eight L2s
+// (8x the fetches), and a scatter leaves every line partially written in eight places.  With this mapping
+// XCD c works on the c-th CONTIGUOUS eighth of the pass, so a chain's lines are fetched / completed once.
+// The launch pads gridDim.x to a multiple of 8 (the kernels' own range checks drop the surplus blocks); if
+// the hardware deals differently nothing breaks, the mapping is a bijection either way.
+__device__ __forceinline__ uint32_t xcd_block() {
+    const uint32_t b = blockIdx.x, per = gridDim.x >> 3;
+    return (b & 7u) * per + (b >> 3);
+}
+
 // Mask of the valid lanes holding the same BITS-bit key as this lane.
 template <int BITS>
 __device__ __forceinline__ uint64_t match_lanes(uint32_t key, bool valid) {
@@ -199,15 +211,78 @@ __device__ __forceinline__ void run_lane_streams(NB_GLOBAL const uint16_t *in, N
 
 // ------------------------------------------------------------------------------------------
 // S1: predictor, activity level, context address.  NBLIC.c:287-410.
-// grid = (ceil(w/256), h); one lane per pixel.  err_prev (the clipped error of the pixel to
-// the left, NBLIC.c:808/:878) is recomputed from the input image -- in lossless mode the
-// reconstruction IS the input, so S1 carries no state at all.
+// In lossless mode the reconstruction IS the input, so S1 carries no state at all: every pixel is
+// a function of the 12 input pixels around it and of the prediction of its left neighbour
+// (err_prev, NBLIC.c:808/:878).  The stage is the one bandwidth-shaped kernel of the path (1 B/px
+// in, a 4-byte record out), so it is written for wide memory operations and few instructions:
+//
+//   k_predict_rows    the interior: a lane owns EIGHT consecutive pixels of one row (columns 8.. of rows
+//                     2..).  Three 16-byte loads (rows i, i-1, i-2, columns j0-4 .. j0+11) give it every tap
+//                     of its run in registers; it predicts the pixel left of the run once (9 predictions
+//                     per 8 pixels, nothing re-read, no cross-lane traffic), walks the run carrying the
+//                     previous prediction, and stores the eight records as two 16-byte stores.  The
+//                     level interpolation's integer divide is a 201-entry LDS table.
+//   k_predict_border  everything with a fall-back tap (rows 0-1; the first 8 and the last 4-11 columns of
+//                     the other rows; images narrower than 20): one lane per pixel, byte loads, the chained
+//                     fall-backs of model.h sample_taps.  < 1 % of a large frame.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_predict(const E1Job *__restrict__ jobs) {
+typedef uint32_t u32x4_any __attribute__((ext_vector_type(4), aligned(1)));    // a 16-byte load / store at any byte address
+typedef uint32_t u32x4_dw __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ int interior_runs(int w) { return w >= 20 ? (w - 12) / 8 : 0; }   // runs of 8 columns from column 8; taps reach j0-4 .. j0+11
+
+__global__ void __launch_bounds__(256) k_predict_rows(const E1Job *__restrict__ jobs) {
+    __shared__ uint16_t qlut[208];                                        // activity (clipped to 200) -> qu | qv << 4 | qw << 8
+    if (threadIdx.x < 208) {
+        const Level L = quantise(threadIdx.x < 200 ? int(threadIdx.x) : 200);
+        qlut[threadIdx.x] = uint16_t(L.qu | (L.qv << 4) | (L.qw << 8));
+    }
+    __syncthreads();
     const E1Job &J = jobs[blockIdx.z];
     const int w = J.w;
-    int j = int(blockIdx.x) * 256 + int(threadIdx.x);
-    int i = int(blockIdx.y);
+    const int run = int(blockIdx.x) * 256 + int(threadIdx.x), i = int(blockIdx.y) + 2;
+    if (i >= J.h || run >= interior_runs(w)) return;
+    const int j0 = 8 + 8 * run;
+    const auto at = gptr(J.b.img) + (size_t(i) * size_t(w) + size_t(j0 - 4));
+    const u32x4 r0 = *(NB_GLOBAL const u32x4_any *)at;
+    const u32x4 r1 = *(NB_GLOBAL const u32x4_any *)(at - w);
+    const u32x4 r2 = *(NB_GLOBAL const u32x4_any *)(at - 2 * size_t(w));
+    auto px = [](const u32x4 &v, int k) { return int((v[k >> 2] >> (8 * (k & 3))) & 0xFFu); };   // k is a constant after unrolling
+    auto taps_at = [&](int c) {                                           // window column c = image column j0 - 4 + c
+        Taps n;
+        n.a = px(r0, c - 1); n.e = px(r0, c - 2);
+        n.b = px(r1, c); n.c = px(r1, c - 1); n.d = px(r1, c + 1); n.q = px(r1, c - 2); n.t = px(r1, c + 2);
+        n.f = px(r2, c); n.g = px(r2, c + 1); n.h = px(r2, c - 1); n.r = px(r2, c + 2); n.s = px(r2, c - 2);
+        return n;
+    };
+    int px_left = predict(taps_at(3));                                    // the pixel left of the run
+    uint32_t rec[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const Taps n = taps_at(4 + q);
+        const int px0 = predict(n);
+        const int delta = activity(n, clip_err(n.a, px_left));
+        const uint32_t e = qlut[delta < 200 ? delta : 200];
+        const Level L{int(e & 15u), int((e >> 4) & 15u), int(e >> 8)};
+        rec[q] = pack_s1(px0, context_address(n, L.qu, px0), L);
+        px_left = px0;
+    }
+    const auto out = gptr(J.b.rec1) + (size_t(i) * size_t(w) + size_t(j0));
+    *(NB_GLOBAL u32x4_dw *)out = u32x4{rec[0], rec[1], rec[2], rec[3]};
+    *(NB_GLOBAL u32x4_dw *)(out + 4) = u32x4{rec[4], rec[5], rec[6], rec[7]};
+}
+
+// top == 1: rows 0 and 1, every column (grid.y = 2);  top == 0: rows 2.., the columns k_predict_rows leaves out
+__global__ void __launch_bounds__(64) k_predict_border(const E1Job *__restrict__ jobs, int top) {
+    const E1Job &J = jobs[blockIdx.z];
+    const int w = J.w;
+    const int i = top ? int(blockIdx.y) : int(blockIdx.y) + 2;
+    int j = int(blockIdx.x) * 64 + int(threadIdx.x);
+    if (!top) {
+        const int first_right = 8 + 8 * interior_runs(w);                 // == w when there is no interior at all
+        if (interior_runs(w) == 0) { if (blockIdx.x) return; }
+        else j = j < 8 ? j : first_right + (j - 8);
+    }
     if (i >= J.h || j >= w) return;
     const auto img = gptr(J.b.img);
     auto pix = [&](int r, int c) { return int(img[size_t(r) * size_t(w) + size_t(c)]); };
@@ -258,7 +333,7 @@ __global__ void __launch_bounds__(256) k_adr_count(const E1Job *__restrict__ job
     const E1Job &J = jobs[blockIdx.y];
     const auto rec1 = gptr(J.b.rec1); const auto table = gptr(J.b.table);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
-    int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+    int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<M::kKeys>(hist, 0);
@@ -281,7 +356,7 @@ __global__ void __launch_bounds__(256) k_adr_scatter(const E1Job *__restrict__ j
     const auto rec1 = gptr(J.b.rec1); const auto x = gptr(J.b.img);
     const auto table = gptr(J.b.table); const auto s2in = gptr(J.b.s2in); const auto pos2 = gptr(J.b.pos2);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
-    int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+    int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *off = lds[threadIdx.x >> 6];
     for (int k = lane_id(); k < M::kKeys; k += 64) off[k] = table[size_t(k) * plan.nseg + seg];
@@ -444,7 +519,7 @@ __global__ void __launch_bounds__(256) k_map_count(const E1Job *__restrict__ job
     const auto pos2 = gptr(J.b.pos2); const auto pxs = gptr(J.b.pxs); const auto table = gptr(J.b.table);
     const auto rec1 = gptr(J.b.rec1);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
-    int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+    int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<512>(hist, 0);
@@ -495,7 +570,7 @@ __global__ void __launch_bounds__(256) k_map_count_pre(const E1Job *__restrict__
     const auto x = gptr(J.b.img); const auto pxs = gptr(J.b.pxs); const auto table = gptr(J.b.table);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
     const NearParams np = near_params(J.near);
-    int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+    int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<512>(hist, 0);
@@ -522,7 +597,7 @@ __global__ void __launch_bounds__(256) k_map_scatter(const E1Job *__restrict__ j
     const auto x = gptr(J.b.img); const auto pxs = gptr(J.b.pxs);
     const auto table = gptr(J.b.table); const auto s3in = gptr(J.b.s3in); const auto pos3 = gptr(J.b.pos3);
     const uint32_t n = J.n; const SegPlan plan = J.pp;
-    int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+    int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *off = lds[threadIdx.x >> 6];
     for (int k = lane_id(); k < 512; k += 64) off[k] = table[size_t(k) * plan.nseg + seg];
@@ -630,7 +705,7 @@ __global__ void __launch_bounds__(256) k_count_bins(const E1Job *__restrict__ jo
     const E1Job &J = jobs[blockIdx.y];
     const auto rec1 = gptr(J.b.rec1); const auto s3out = gptr(J.b.s3out);
     const auto pos3 = gptr(J.b.pos3); const auto z = gptr(J.b.z); const auto cnt = gptr(J.b.cnt);
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t t = xcd_block() * 256u + threadIdx.x;
     if (t >= J.n) return;
     Level L = s1_level(rec1[t]);
     uint32_t p = pos3[t];
@@ -646,7 +721,7 @@ __global__ void __launch_bounds__(256) k_emit_bins(const E1Job *__restrict__ job
     const E1Job &J = jobs[blockIdx.y];
     const auto rec1 = gptr(J.b.rec1); const auto z = gptr(J.b.z);
     const auto ev_off = gptr(J.b.ev_off); const auto events = gptr(J.b.events);
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t t = xcd_block() * 256u + threadIdx.x;
     if (t >= J.n) return;
     Level L = s1_level(rec1[t]);
     auto out = events + ev_off[t];
@@ -688,7 +763,7 @@ __global__ void __launch_bounds__(256) k_touch_count(const E1Job *__restrict__ j
     const E1Job &J = jobs[blockIdx.y];
     const auto events = gptr(J.b.events); const auto table = gptr(J.b.table);
     const uint32_t n_ev = J.n_ev; const SegPlan plan = J.pe;
-    int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+    int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<4096>(hist, 0);
@@ -748,7 +823,7 @@ __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__
     const uint32_t n_ev = J.n_ev; const SegPlan plan = J.pe;
     const int parity = int(blockIdx.z);
     const auto posP = (NB_GLOBAL uint32_t *)gptr(J.b.tpos) + size_t(parity) * ((size_t(n_ev) + 63) & ~size_t(63));
-    const int seg = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+    const int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
     TouchLds &L = lds[threadIdx.x >> 6];
     const int lane = lane_id();
@@ -1121,7 +1196,7 @@ __global__ void __launch_bounds__(256) k_mix(const E1Job *__restrict__ jobs) {
     const auto events = gptr(J.b.events); const auto tout = gptr(J.b.tout);
     const auto pos0 = (NB_GLOBAL const uint32_t *)gptr(J.b.tpos); const auto coded = gptr(J.b.coded);
     const auto pos1 = pos0 + ((size_t(J.n_ev) + 63) & ~size_t(63));
-    uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    uint32_t r = xcd_block() * 256u + threadIdx.x;
     if (r >= J.n_ev) return;
     uint32_t e = events[r];
     // k_touch_scatter files positions by tree PARITY; tree u is the one with qu's parity, and an
@@ -1247,7 +1322,9 @@ __global__ void __launch_bounds__(256) k_q_symbols(const E1Job *__restrict__ job
     for (int k = int(threadIdx.x); k < 12 * 256; k += 256) hist[k] = 0;
     __syncthreads();
     const uint32_t n = J.n;
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+    const uint32_t per_block = ((n + gridDim.x - 1) / gridDim.x + 255u) & ~255u;      // a contiguous run of pixels per block, XCD-contiguous
+    const uint32_t t_lo = xcd_block() * per_block, t_hi = min(n, t_lo + per_block);
+    for (uint32_t t = t_lo + threadIdx.x; t < t_hi; t += 256u) {
         const uint32_t r = rec1[t];
         const int vs = int(int16_t(s2out[pos2[t]]));                 // context state >> 10 as the chain saw it
         const int sign = vs & 1, qd = int(r >> 16);
@@ -1284,6 +1361,7 @@ int e1_selftest(hipStream_t s) {
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 static inline unsigned cdiv(size_t a, size_t b) { return unsigned((a + b - 1) / b); }
+static inline unsigned pad8(unsigned v) { return (v + 7u) & ~7u; }       // grids of kernels that use xcd_block()
 
 struct Marker {                       // records one event in front of every launch
     E1Timers *tm; hipStream_t s; int k;
@@ -1317,10 +1395,13 @@ void e1_launch_front(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipSt
         max_w = h_jobs[k].w > max_w ? h_jobs[k].w : max_w; max_h = h_jobs[k].h > max_h ? h_jobs[k].h : max_h;
         max_n = h_jobs[k].n > max_n ? h_jobs[k].n : max_n; max_nseg = h_jobs[k].pp.nseg > max_nseg ? h_jobs[k].pp.nseg : max_nseg;
     }
-    const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs), px_grid(cdiv(max_n, 256), n_jobs);
+    const dim3 seg_grid(pad8(cdiv(max_nseg, 4)), n_jobs), px_grid(pad8(cdiv(max_n, 256)), n_jobs);
     Marker mark{tm, s, 0};
     mark(); hipLaunchKernelGGL(k_init_state, dim3(16, n_jobs), dim3(256), 0, s, d_jobs);
-    mark(); hipLaunchKernelGGL(k_predict, dim3(cdiv(max_w, 256), max_h, n_jobs), dim3(256), 0, s, d_jobs);
+    mark();                                                     // one timed stage "k_predict": interior rows + the two border launches
+    if (max_h > 2 && max_w >= 20) hipLaunchKernelGGL(k_predict_rows, dim3(cdiv((max_w - 12) / 8, 256), max_h - 2, n_jobs), dim3(256), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_predict_border, dim3(cdiv(max_w, 64), max_h < 2 ? max_h : 2, n_jobs), dim3(64), 0, s, d_jobs, 1);
+    if (max_h > 2) hipLaunchKernelGGL(k_predict_border, dim3(1, max_h - 2, n_jobs), dim3(64), 0, s, d_jobs, 0);
     mark(); hipLaunchKernelGGL(k_adr_count<NbModel>, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<0>(d_jobs, n_jobs, uint32_t(kContexts) * max_nseg, s, mark);
     mark(); hipLaunchKernelGGL(k_adr_scatter<NbModel>, seg_grid, dim3(256), 0, s, d_jobs);
@@ -1345,7 +1426,7 @@ void e1_launch_front_pre(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, h
     for (int k = 0; k < n_jobs; k++) {
         max_n = h_jobs[k].n > max_n ? h_jobs[k].n : max_n; max_nseg = h_jobs[k].pp.nseg > max_nseg ? h_jobs[k].pp.nseg : max_nseg;
     }
-    const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs), px_grid(cdiv(max_n, 256), n_jobs);
+    const dim3 seg_grid(pad8(cdiv(max_nseg, 4)), n_jobs), px_grid(pad8(cdiv(max_n, 256)), n_jobs);
     Marker mark{nullptr, s, 0};
     hipLaunchKernelGGL(k_map_count_pre, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<1>(d_jobs, n_jobs, 512u * max_nseg, s, mark);
@@ -1366,11 +1447,11 @@ void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
         max_n = h_jobs[k].n > max_n ? h_jobs[k].n : max_n; max_ev = h_jobs[k].n_ev > max_ev ? h_jobs[k].n_ev : max_ev;
         max_nseg = h_jobs[k].pe.nseg > max_nseg ? h_jobs[k].pe.nseg : max_nseg;
     }
-    const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs);
+    const dim3 seg_grid(pad8(cdiv(max_nseg, 4)), n_jobs);
     Marker mark{tm, s, 21};
     mark();
-    if (general) hipLaunchKernelGGL(k_emit_bins<true>, dim3(cdiv(max_n, 256), n_jobs), dim3(256), 0, s, d_jobs);
-    else hipLaunchKernelGGL(k_emit_bins<false>, dim3(cdiv(max_n, 256), n_jobs), dim3(256), 0, s, d_jobs);
+    if (general) hipLaunchKernelGGL(k_emit_bins<true>, dim3(pad8(cdiv(max_n, 256)), n_jobs), dim3(256), 0, s, d_jobs);
+    else hipLaunchKernelGGL(k_emit_bins<false>, dim3(pad8(cdiv(max_n, 256)), n_jobs), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_touch_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<3>(d_jobs, n_jobs, 4096u * max_nseg, s, mark);
     mark(); hipLaunchKernelGGL(k_touch_scatter, dim3(seg_grid.x, seg_grid.y, 2), dim3(256), 0, s, d_jobs);
@@ -1378,7 +1459,7 @@ void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
     mark(); hipLaunchKernelGGL(k_counter_epochs, dim3(4096, n_jobs), dim3(64), 0, s, d_jobs);
     const unsigned max_windows = unsigned(2ull * max_ev / kWin) + 4096u;          // every touch list has <= 2 touches per bin
     mark(); hipLaunchKernelGGL(k_counter_probs, dim3(cdiv(max_windows, 4), n_jobs), dim3(256), 0, s, d_jobs);
-    mark(); hipLaunchKernelGGL(k_mix, dim3(cdiv(max_ev, 256) ? cdiv(max_ev, 256) : 1, n_jobs), dim3(256), 0, s, d_jobs);
+    mark(); hipLaunchKernelGGL(k_mix, dim3(pad8(cdiv(max_ev, 256) ? cdiv(max_ev, 256) : 1), n_jobs), dim3(256), 0, s, d_jobs);
     mark();                                                     // index 31: end
 }
 
@@ -1388,7 +1469,7 @@ void q_launch_model(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
         max_w = h_jobs[k].w > max_w ? h_jobs[k].w : max_w; max_h = h_jobs[k].h > max_h ? h_jobs[k].h : max_h;
         max_n = h_jobs[k].n > max_n ? h_jobs[k].n : max_n; max_nseg = h_jobs[k].pp.nseg > max_nseg ? h_jobs[k].pp.nseg : max_nseg;
     }
-    const dim3 seg_grid(cdiv(max_nseg, 4), n_jobs);
+    const dim3 seg_grid(pad8(cdiv(max_nseg, 4)), n_jobs);
     Marker mark{nullptr, s, 0};
     hipLaunchKernelGGL(k_init_state, dim3(16, n_jobs), dim3(256), 0, s, d_jobs);
     hipLaunchKernelGGL(k_q_predict, dim3(cdiv(max_w, 256), max_h, n_jobs), dim3(256), 0, s, d_jobs);
@@ -1400,7 +1481,7 @@ void q_launch_model(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
     hipLaunchKernelGGL(k_bias_blocks<QModel>, dim3(cdiv(max_blocks, 64), n_jobs), dim3(64), 0, s, d_jobs);
     hipLaunchKernelGGL(k_bias_fixup<QModel>, dim3(3072 / 64, n_jobs), dim3(64), 0, s, d_jobs);
     unsigned sym_blocks = cdiv(max_n, 256 * 16);                      // 16 pixels per thread: fewer global histogram merges
-    hipLaunchKernelGGL(k_q_symbols, dim3(sym_blocks ? sym_blocks : 1, n_jobs), dim3(256), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_q_symbols, dim3(pad8(sym_blocks ? sym_blocks : 1), n_jobs), dim3(256), 0, s, d_jobs);
 }
 
 }  // namespace nblic

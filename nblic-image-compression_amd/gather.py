@@ -28,9 +28,10 @@ def gather_packed(payload: torch.Tensor, lens: torch.Tensor, group=None, dst: in
     payload : 1-D uint8 tensor (on the communication device) holding this rank's streams back to
               back; lens : 1-D int64 tensor of their lengths on the same device.
     Rank ``dst`` gets ``(payloads, lengths)``: per rank a uint8 tensor trimmed to its byte count
-    and its int64 length vector, both still on the device; other ranks get None.  Two
-    collectives in all: one all_gather of the (padded) length vectors, one padded gather of the
-    payload -- each non-root GPU sends straight to the root over its own xGMI link.
+    and its int64 length vector, both still on the device; other ranks get None.  Three
+    collectives in all: a tiny all_gather of (image count, payload bytes) that sizes the padding, one
+    all_gather of the padded length vectors, and one padded gather of the payload -- the only one that
+    carries data, each non-root GPU sending straight to the root over its own xGMI link.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)

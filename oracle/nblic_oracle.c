@@ -9,7 +9,7 @@
  *
  * Parity status: PINNED against oracle/_ref/libnblic_ref.so (the unmodified
  * reference compiled by oracle/Makefile) and tests/golden/ fixtures; see
- * tests/test_oracle_vs_reference.py and tests/test_golden.py.
+ * tests/test_oracle.py (golden fixtures, live compares with the compiled reference, Kodak).
  *
  * Layout of this file
  *   lsq_*      integer weighted-least-squares predictor ("AVP", NBLIC.c:112-283)

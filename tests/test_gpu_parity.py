@@ -207,7 +207,7 @@ def test_config3_kodak_shaped_batch(gpu_ctx, oracle):
     imgs = [syn1(h, w, seed) for seed, (h, w) in enumerate(shapes, start=1)]
     got = gpu_ctx.encode_batch(imgs)
     gotq = gpu_ctx.qencode_batch(imgs[:6] + imgs[-3:])
-    for k in (0, 5, 11, 17, 18, 23):
+    for k in range(24):                                                   # all 24, like the Kodak set itself on the CPU side
         assert got[k] == oracle.encode(imgs[k], 0, 1)[0], k
     assert len(set(got)) == 24
     for g, im in zip(gotq, imgs[:6] + imgs[-3:]):
@@ -420,3 +420,47 @@ def test_dropin_limit_is_opt_in(pkg):
     finally:
         pkg.set_default_max_pixels(0)
     assert lib.NBLICcompress(0, out.ctypes.data_as(u8p), img.ctypes.data_as(u8p), 2, 3, C.byref(n), C.byref(e)) > 0
+
+
+def test_soak_random_contexts_and_batches(pkg, oracle):
+    """Bounded soak (~20 rounds): random context shapes, chunk lengths, image sizes, contents and MODES,
+    synchronous and overlapping batches, effort-0 batches and batch decodes through the same context."""
+    import os
+    rng = np.random.default_rng(20261004)
+    modes = [(0, 1), (0, 1), (0, 1), (2, 1), (0, 2), (1, 3), (9, 1), (4, 2)]
+    for rnd in range(20):
+        groups, gsize, coders = int(rng.integers(1, 7)), int(rng.integers(1, 9)), int(rng.integers(1, 17))
+        os.environ["NBLIC_AMD_CHUNK_BINS"] = str(int(rng.choice([4096, 10000, 65536, 262144, 1 << 22])))
+        try:
+            ctx = pkg.Context(device=0, n_slots=groups * gsize, n_coders=coders, n_groups=groups, n_host_buffers=int(rng.integers(8, 200)))
+        finally:
+            del os.environ["NBLIC_AMD_CHUNK_BINS"]
+        try:
+            batches = []
+            for b in range(int(rng.integers(1, 4))):
+                imgs = []
+                for k in range(int(rng.integers(1, 40))):
+                    big = rng.random() < 0.08
+                    h, w = (int(rng.integers(300, 700)), int(rng.integers(300, 900))) if big else (int(rng.integers(1, 120)), int(rng.integers(1, 160)))
+                    c = inputs.CONTENTS[int(rng.integers(0, len(inputs.CONTENTS)))]
+                    imgs.append(inputs.make(c, h, w) if c != "syn1" else inputs.syn1(h, w, seed=int(rng.integers(1, 1000))))
+                batches.append(imgs)
+            if rng.random() < 0.5:
+                tickets = [ctx.encode_begin([i.ctypes.data for i in imgs], [i.shape for i in imgs], False) for imgs in batches]
+                for b in rng.permutation(len(batches)):
+                    outs, lens = ctx.encode_end(tickets[b])
+                    assert [x[:int(n)].tobytes() for x, n in zip(outs, lens)] == [oracle.encode(i, 0, 1)[0] for i in batches[b]], (rnd, b)
+            else:
+                for b, imgs in enumerate(batches):
+                    small = [i for i in imgs if i.size <= 20000][:12] or imgs[:1]
+                    md = [modes[int(rng.integers(0, len(modes)))] for _ in small]
+                    streams, recs = ctx.encode_modes(small, [m[0] for m in md], [m[1] for m in md])
+                    dec = ctx.decode_batch(streams)
+                    for img, m, s, r, d in zip(small, md, streams, recs, dec):
+                        ws, wrec, *_ = oracle.encode(img, m[0], m[1])
+                        assert s == ws and np.array_equal(r, wrec) and d is not None and np.array_equal(d[0], wrec), (rnd, b, img.shape, m)
+            if rng.random() < 0.3:
+                q = batches[0][:6]
+                assert ctx.qencode_batch(q) == [oracle.qencode(i) for i in q], rnd
+        finally:
+            ctx.close()
