@@ -80,7 +80,7 @@ def profiled_traffic(kernel, images_per_launch):
     prof_ipl = float(meta.get("images_per_launch", 8))
     for row in csv.DictReader(open(files[-1])):
         if row["kernel"].split("(")[0].split("::")[-1] == kernel:
-            return int(float(row["hbm_MB_per_launch_corrected(2*fetch+write)"]) * 1048576 * images_per_launch / prof_ipl)
+            return int(float(row["hbm_MB_per_launch_corrected(factor*fetch+write)"]) * 1048576 * images_per_launch / prof_ipl)
     return None
 
 
@@ -109,6 +109,29 @@ def launch_ranks(n_gpus, backend):
     sys.exit(rc)
 
 
+def cpu_share(local_rank, gpus_per_node):
+    """The logical CPUs of this rank's 1/gpus_per_node slice of the host: whole physical cores (both SMT
+    siblings), consecutive core ids (cores 16r .. 16r+15 of a 128-core, 8-GPU box are on GPU r's socket).
+    At N = 1 the rank still takes only its eighth, so the single-GPU figure is what a rank of the 8-GPU
+    job gets.  Returns None when the topology cannot be read."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        cores = {}
+        for c in avail:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                sib = f.read().strip()
+            first = int(sib.replace("-", ",").split(",")[0])
+            cores.setdefault(first, []).append(c)
+        ordered = [cores[k] for k in sorted(cores)]
+        per = len(ordered) // gpus_per_node
+        if per < 1:
+            return None
+        mine = ordered[(local_rank % gpus_per_node) * per:(local_rank % gpus_per_node + 1) * per]
+        return sorted(c for core in mine for c in core)
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
 def host_description():
     model = "unknown"
     try:
@@ -125,7 +148,7 @@ def host_description():
         cpus = os.cpu_count() or 1
     toggles = {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "NBLIC_AMD_HOSTMALLOC", "NBLIC_AMD_CHUNK_BINS", "NBLIC_AMD_DBG",
                                           "NBLIC_AMD_NO_SIMD", "NBLIC_AMD_DEVICE", "NBLIC_BENCH_DEVICE") if k in os.environ}
-    return {"cpu_model": model, "cpus_available": cpus, "cpus_total": os.cpu_count(), "env": toggles}
+    return {"cpu_model": model, "cpus_used_by_this_rank": cpus, "cpus_total": os.cpu_count(), "env": toggles}
 
 
 def main():
@@ -148,6 +171,7 @@ def main():
                          "run of steps, inside the timed region, instead of once per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 path be rehearsed with every rank on one GPU")
+    ap.add_argument("--node-gpus", type=int, default=8, help="GPUs the host is shared between: a rank confines itself (threads and all) to 1/NODE_GPUS of the host's cores, both SMT siblings of each; 0 = no confinement")
     ap.add_argument("--launch-check", action="store_true", help="no GPU work: every rank joins a gloo group, rank 0 prints how many ranks it saw (tests the --gpus N launcher on a CPU-only box)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed extra measurements (single frame, 8-frame batch, host inputs)")
     args = ap.parse_args()
@@ -158,6 +182,12 @@ def main():
     if env_world is not None and int(env_world) != args.gpus:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a mislabelled run", file=sys.stderr)
         sys.exit(2)
+
+    share = None
+    if args.node_gpus > 0 and not args.launch_check:
+        share = cpu_share(int(os.environ.get("LOCAL_RANK", "0")), max(args.node_gpus, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+        if share:
+            os.sched_setaffinity(0, share)              # before torch / HIP start their threads: they inherit it
 
     import numpy as np
     import torch
@@ -196,14 +226,17 @@ def main():
     except AttributeError:
         cpus = os.cpu_count() or 1
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    coders = args.coders or max(1, min(B, 16, cpus // max(1, local_world)))   # 16 = one GPU's CPU share
+    if share:
+        coders = args.coders or max(1, min(B, len(share)))                   # one coder thread per logical CPU of the rank's slice
+    else:
+        coders = args.coders or max(1, min(B, 16, cpus // max(1, local_world)))   # 16 = one GPU's CPU share
     slots = args.slots or min(B, 48)
 
     # frames are generated and uploaded 128 at a time: only the CPU baseline's sample (and, with
     # --host-inputs, everything) stays on the host
     from concurrent.futures import ThreadPoolExecutor
     frames, dev_frames = [], []
-    with ThreadPoolExecutor(max_workers=max(1, min(16, cpus // max(1, local_world)))) as ex:   # the C generator releases the GIL
+    with ThreadPoolExecutor(max_workers=max(1, min(16, cpus if share else cpus // max(1, local_world)))) as ex:   # the C generator releases the GIL
         for k0 in range(0, B, 128):
             part = list(ex.map(lambda k: pkg.syn1(H, W, seed=rank * B + k + 1), range(k0, min(B, k0 + 128))))
             dev_frames += [torch.from_numpy(f).to(dev) for f in part]

@@ -444,8 +444,32 @@ struct CoderThread {
         if (d_rows) hipFree(d_rows);
         for (auto &e : ev) if (e) hipEventDestroy(e);
     }
-    uint16_t *slot(size_t chunk, int lane) { return ring + (size_t(chunk % kRingDepth) * kMaxTake + size_t(lane)) * kChunkBins; }
-    uint64_t *rows(size_t chunk) { return reinterpret_cast<uint64_t *>(ring) + size_t(chunk % kRingDepth) * (kChunkBins / 4 * kMaxTake); }   // same bytes as the lanes' slots
+    // The ring holds kRingDepth slots of ring_lanes x ring_chunk bins; it is sized by what the thread has actually been
+    // asked to code (one lane for an image coded alone, sixteen for a pack pair; the chunk no longer than the longest
+    // image) and only grows: a context that codes one small image through the drop-in entry points pins kilobytes,
+    // the bench's threads end up at 2 x 16 x 4 Mbin x 2 B = 256 MB each.
+    size_t ring_lanes = 0, ring_chunk = 0, rows_cap = 0;
+    bool ensure_ring(size_t lanes, size_t chunk, bool need_rows) {
+        chunk = (chunk + 4095) & ~size_t(4095);
+        if (lanes > ring_lanes || chunk > ring_chunk) {
+            const size_t nl = lanes > ring_lanes ? lanes : ring_lanes, nc = chunk > ring_chunk ? chunk : ring_chunk;
+            locked_free(ring);
+            ring = locked_alloc(kRingDepth * nl * nc);
+            if (!ring) { ring_lanes = ring_chunk = 0; fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
+            ring_lanes = nl; ring_chunk = nc;
+        }
+        const size_t want_rows = need_rows ? kRingDepth * (ring_chunk / 4 * kMaxTake) : 0;
+        if (want_rows > rows_cap) {
+            if (d_rows) hipFree(d_rows);
+            d_rows = nullptr; rows_cap = 0;
+            HIP_OK(hipMalloc((void **)&d_rows, want_rows * sizeof(uint64_t)));
+            rows_cap = want_rows;
+        }
+        return true;
+    }
+    uint16_t *slot(size_t chunk, int lane) { return ring + (size_t(chunk % kRingDepth) * ring_lanes + size_t(lane)) * ring_chunk; }
+    uint64_t *rows(size_t chunk) { return reinterpret_cast<uint64_t *>(ring) + size_t(chunk % kRingDepth) * (ring_chunk / 4 * kMaxTake); }   // same bytes as the lanes' slots
+    uint64_t *dev_rows(size_t chunk) { return d_rows + size_t(chunk % kRingDepth) * (ring_chunk / 4 * kMaxTake); }
 };
 
 // Streams `take` images' bins from HBM and codes them: one image with the scalar coder, up to
@@ -453,10 +477,9 @@ struct CoderThread {
 // lens[k] = coder bytes or SIZE_MAX.
 static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size_t *n, int take, uint8_t *const *dst,
                           const size_t *caps, size_t *lens, size_t chunk_bins) {
-    if (!t.ring && !(t.ring = locked_alloc(kRingDepth * kMaxTake * kChunkBins))) { fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
-    if (take > 1 && !t.d_rows) HIP_OK(hipMalloc((void **)&t.d_rows, kRingDepth * (kChunkBins / 4 * kMaxTake) * sizeof(uint64_t)));
     size_t n_max = 0;
     for (int k = 0; k < take; k++) n_max = n[k] > n_max ? n[k] : n_max;
+    if (!t.ensure_ring(take > 1 ? size_t(kMaxTake) : 1, n_max < chunk_bins ? n_max + 4 : chunk_bins, take > 1)) return false;
     const size_t chunks = (n_max + chunk_bins - 1) / chunk_bins;                     // chunk_bins <= kChunkBins, the ring's slot size
     auto chunk_len = [&](size_t c, int k) { const size_t off = c * chunk_bins; return off >= n[k] ? size_t(0) : (n[k] - off < chunk_bins ? n[k] - off : chunk_bins); };
     // two packs in lock-step whenever there is more than one image: a lone pack is bound by the
@@ -476,7 +499,7 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
                 longest = len > longest ? len : longest;
             }
             const uint32_t n_rows = uint32_t((longest + 3) / 4);
-            uint64_t *d = t.d_rows + size_t(c % kRingDepth) * (kChunkBins / 4 * kMaxTake);
+            uint64_t *d = t.dev_rows(c);
             if (n_rows) {
                 hipLaunchKernelGGL(k_interleave16, dim3((n_rows * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_rows);
                 HIP_OK(hipGetLastError());

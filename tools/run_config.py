@@ -23,6 +23,15 @@ elif args.config == 5:
     h, w, near, effort = 16384, 16384, 0, 3
 else:
     h, w = map(int, args.shape.split("x")); near, effort = args.near, args.effort
+import threading
+
+def heartbeat():                                        # a long single-image run prints nothing for minutes: keep a sign of life on stderr
+    t0 = time.time()
+    while True:
+        time.sleep(45)
+        print(f"[run_config] still running, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+
+threading.Thread(target=heartbeat, daemon=True).start()
 pkg = importlib.import_module("nblic-image-compression_amd")
 img = pkg.syn1(h, w, 1)
 key = f"syn1s1_{h}x{w}_n{near}_e{effort}"
