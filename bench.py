@@ -228,7 +228,7 @@ def main():
         cpus = os.cpu_count() or 1
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if share:
-        coders = args.coders or max(1, min(B, len(share)))                   # one coder thread per logical CPU of the rank's slice
+        coders = args.coders or max(1, min(B, 16, (len(share) + 1) // 2))    # one coder thread per physical CORE of the slice (measured: 32 threads on 16 cores + SMT siblings 3918 vs 5210 Mpx/s)
     else:
         coders = args.coders or max(1, min(B, 16, cpus // max(1, local_world)))   # 16 = one GPU's CPU share
     slots = args.slots or min(B, 48)

@@ -990,7 +990,7 @@ static bool decode_batch(nblic_amd_ctx *c, int n, const unsigned char *const *st
     for (int i0 = 0; i0 < m;) {
         int i1 = i0 + 1;
         while (i1 < m && items[size_t(i1)].kind == items[size_t(i0)].kind && items[size_t(i1)].effort == items[size_t(i0)].effort) i1++;
-        const bool ok = items[size_t(i0)].kind == 1 ? serial_qdecode_launch(c->dec_jobs + i0, i1 - i0, st)
+        const bool ok = items[size_t(i0)].kind == 1 ? serial_qdecode_launch(c->dec_jobs + i0, jobs.data() + i0, i1 - i0, st)
                                                     : serial_decode_launch(c->dec_jobs + i0, jobs.data() + i0, i1 - i0, st);
         if (!ok) { fprintf(stderr, "[nblic_amd] decode launch failed\n"); hipStreamSynchronize(st); return false; }
         i0 = i1;

@@ -41,7 +41,7 @@ inline size_t stats_doubles(int effort, int w) { return size_t(2) * size_t(w) * 
 // d_jobs[0..n): all of one effort (1, 2 or 3); h_jobs: host copy, read to size the launch
 bool serial_model_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s);
 bool serial_decode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s);
-bool serial_qdecode_launch(const SerialJob *d_jobs, int n, hipStream_t s);
+bool serial_qdecode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s);
 int serial_selftest(hipStream_t s);                    // device check of the double-carried divisions against 64-bit integers; 0 = pass
 
 }  // namespace nblic

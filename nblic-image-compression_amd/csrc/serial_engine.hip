@@ -517,7 +517,7 @@ struct StreamWindow {
     }
     __device__ void start(const uint8_t *b, size_t n, size_t at, uint32_t *buf) {
         base = b; len = n; pos = at; sbuf = buf; overrun = false;
-        fill_half(0); fill_half(512);
+        fill_half(at & ~size_t(511)); fill_half((at & ~size_t(511)) + 512);
         wave_sync();
     }
     __device__ __forceinline__ uint32_t next() {
@@ -648,42 +648,82 @@ __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restric
     else decode_body<N, false>(S, rows, J, rs);
 }
 
-// ---- QNBLIC decoder (QNBLIC.c:493-555): context table + frequency tables in LDS, one image per wave ----
-__global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restrict__ jobs) {
-    __shared__ int ctx[3072];
-    __shared__ uint32_t freq[12 * 256], start[12 * 256];
+// ---- QNBLIC decoder (QNBLIC.c:493-555): one image per wave, every lane computing the same pixel -------
+// Context table, the twelve frequency / cumulative tables (16-bit: the histograms are normalised to 2^15)
+// and a coarse symbol index live in LDS: a symbol is found from the rANS state's low 15 bits by one coarse
+// lookup (the symbol of slot low & ~127) plus a short walk along the cumulative table, instead of a read
+// of the 384 KB slot table in memory on the pixel's critical path.  Taps: rows >= 2 use the sliding window
+// (QNBLIC's window neighbourhood equals direct sampling there except a / e at the row start);
+// rows 0 and 1 use the closed form of model.h sample_taps_q.
+struct QDecodeLds {
+    int ctx[3072];
+    uint16_t freq[12 * 256], start[12 * 256 + 1];
+    uint8_t coarse[12][256];
+    uint32_t sbuf[256];
+};
+
+__global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restrict__ jobs, int dyn_bytes) {
+    __shared__ QDecodeLds S;
+    extern __shared__ __align__(16) uint8_t rows[];
     const SerialJob &J = jobs[blockIdx.x];
-    for (int k = int(threadIdx.x); k < 3072; k += 64) { ctx[k] = 0; freq[k] = J.q_freq[k]; start[k] = J.q_start[k]; }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    const int w = J.w;
-    uint8_t *img = J.recon;
-    const uint16_t *words = reinterpret_cast<const uint16_t *>(J.stream);
-    auto pix = [&](int r, int c) { return int(img[size_t(r) * size_t(w) + size_t(c)]); };
-    size_t pos = J.q_pos;
-    bool bad = pos + 2 > J.q_words;
-    uint32_t x = bad ? 0u : ((uint32_t(words[pos]) << 16) | words[pos + 1]);
-    pos += 2;
-    for (int i = 0; i < J.h && !bad; i++) {
+    const int lane = int(threadIdx.x), w = J.w, h = J.h;
+    const auto out = gp(J.recon);
+    for (int k = lane; k < 3072; k += 64) {
+        S.ctx[k] = 0; S.freq[k] = uint16_t(gp(J.q_freq)[k]); S.start[k] = uint16_t(gp(J.q_start)[k]);
+        (&S.coarse[0][0])[k] = gp(J.q_slot)[size_t(k >> 8) * 32768 + size_t(k & 255) * 128];
+    }
+    if (lane == 0) S.start[3072] = 0;
+    wave_sync();
+    const int rs = (w + 15) & ~15;
+    const bool cached = 3 * rs <= dyn_bytes;
+    StreamWindow sw;
+    sw.start(J.stream, J.q_words * 2, J.q_pos * 2, S.sbuf);
+    auto next_word = [&]() { const uint32_t lo = sw.next(); return lo | (sw.next() << 8); };
+    uint32_t x = next_word() << 16;
+    x |= next_word();
+    for (int i = 0; i < h; i++) {
+        uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
+        auto pix = [&](int r, int c) {
+            if (cached) return int((r == i ? r0 : (r == i - 1 ? r1 : r2))[c]);
+            return int(out[size_t(r) * size_t(w) + size_t(c)]);
+        };
+        const size_t row_at = size_t(i) * size_t(w);
+        const bool windowed = cached && i >= 2;
+        TapWindow tw;
+        int u0 = 0;
+        if (windowed) { tw.row_start(r0, r1, r2, w); u0 = r1[0]; }
         int err = 0;
         for (int j = 0; j < w; j++) {
-            const Taps n = sample_taps_q(pix, w, i, j);
+            Taps n;
+            if (windowed) {
+                n.a = j >= 1 ? tw.A : u0; n.e = j >= 2 ? tw.E : u0;
+                n.b = tw.B; n.c = tw.C; n.d = tw.D; n.q = tw.Q; n.f = tw.F; n.g = tw.G; n.h = tw.H; n.r = tw.R; n.s = tw.S; n.t = 0;
+            } else {
+                n = sample_taps_q(pix, w, i, j);
+            }
             const int px0 = predict_q(n), qd = level_q(n, err);
             const int adr = context_address_q(n, qd, px0);
-            const int v = ctx[adr];
+            const int v = S.ctx[adr];
             const int sign = (v >> 10) & 1;
             const int px = iclip(px0 + (v >> 11) + sign, 0, kMaxVal);
             const uint32_t low = x & 32767u;
-            const int y = J.q_slot[size_t(qd) * 32768 + low];
-            x = (x >> 15) * freq[qd * 256 + y] + low - start[qd * 256 + y];
-            if (x < 65536u) { if (pos >= J.q_words) { bad = true; break; } x = (x << 16) | words[pos++]; }
+            int y = S.coarse[qd][low >> 7];
+            while (y < 255 && uint32_t(S.start[qd * 256 + y + 1]) <= low) y++;      // symbols with no slots are stepped over; cumulative starts are <= 2^15
+            x = (x >> 15) * uint32_t(S.freq[qd * 256 + y]) + low - uint32_t(S.start[qd * 256 + y]);
+            if (x < 65536u) x = (x << 16) | next_word();
             const int px_out = symbol_to_pixel(y, px, sign, 0);
-            img[size_t(i) * size_t(w) + size_t(j)] = uint8_t(px_out);
             err = px_out - px0;
-            ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
+            S.ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
+            if (cached) { r0[j] = uint8_t(px_out); if (windowed) tw.advance(r1, r2, w, j, px_out); } else out[row_at + j] = uint8_t(px_out);
+            if (sw.overrun) break;
         }
+        if (cached) {
+            wave_sync();
+            for (int c = lane; c < w; c += 64) out[row_at + c] = r0[c];
+        }
+        if (sw.overrun) break;
     }
-    *J.status = bad ? -1 : 0;
+    if (lane == 0) *J.status = (sw.overrun || J.q_words == 0) ? -1 : 0;
 }
 
 // ---- self-test: the double-carried divisions against 64-bit integers ------------------------------
@@ -761,10 +801,9 @@ bool serial_decode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int 
     }
 }
 
-bool serial_qdecode_launch(const SerialJob *d_jobs, int n, hipStream_t s) {
+bool serial_qdecode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
     if (n <= 0) return true;
-    hipLaunchKernelGGL(k_serial_qdecode, dim3(unsigned(n)), dim3(64), 0, s, d_jobs);
-    return hipGetLastError() == hipSuccess;
+    return launch_rows(k_serial_qdecode, sizeof(QDecodeLds), d_jobs, h_jobs, n, s);
 }
 
 }  // namespace nblic

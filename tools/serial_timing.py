@@ -36,4 +36,12 @@ for mode in args.modes.split(","):
         line["reference_thread_us_per_px"] = round(tr / (H * W) * 1e6, 3)
         line["bit_exact"] = (rs == s1[0])
     print(json.dumps(line), flush=True)
+# effort 0 (QNBLIC): batch decode
+imgs = [syn1(H, W, k + 1) for k in range(args.batch)]
+q = ctx.qencode_batch(imgs)
+t0 = time.perf_counter(); d1 = ctx.decode_batch(q[:1]); td1 = time.perf_counter() - t0
+t0 = time.perf_counter(); db = ctx.decode_batch(q); tdb = time.perf_counter() - t0
+print(json.dumps({"mode": "-e0 decode (QNBLIC)", "size": f"{H}x{W}", "decode_one_us_per_px": round(td1 / (H * W) * 1e6, 3),
+                  "decode_batch": args.batch, "decode_batch_Mpx_s": round(args.batch * H * W / tdb / 1e6, 2),
+                  "decode_ok": all(d is not None and (d[0] == im).all() for d, im in zip(db, imgs))}), flush=True)
 ctx.close()
