@@ -170,6 +170,9 @@ def main():
                     help="collect every step before submitting the next (default: step k+1 is submitted with nblic_amd_encode_batch_begin "
                          "before step k is collected, as a continuous feed would; the pipeline's fill and drain are then paid once per "
                          "run of steps, inside the timed region, instead of once per step)")
+    ap.add_argument("--device-packs", type=int, default=6, help="pack threads of the device range coder (64 images per wave, one lane per image), a supplement to the host coder threads; 0 = host threads only")
+    ap.add_argument("--steps-in-flight", type=int, default=0, help="steps submitted ahead of the one being collected (0 = 4 with the device coder, else 2)")
+    ap.add_argument("--device-min-outstanding", type=int, default=-1, help="images that must be unfinished for the device coder to take a pack (-1 = 2.8 x batch: its seconds of latency never become the tail of the run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 path be rehearsed with every rank on one GPU")
     ap.add_argument("--node-gpus", type=int, default=8, help="GPUs the host is shared between: a rank confines itself (threads and all) to 1/NODE_GPUS of the host's cores, both SMT siblings of each; 0 = no confinement")
@@ -243,19 +246,25 @@ def main():
             dev_frames += [torch.from_numpy(f).to(dev) for f in part]
             torch.cuda.synchronize()
             frames += part if args.host_inputs else part[: max(0, 8 - len(frames))]
-    host_buffers = args.host_buffers or min(B + 16, slots + 16 * coders + 32)   # groups in flight + every thread's sixteen + a queue
+    dev_packs = args.device_packs if (args.overlap_steps and B >= 256) else 0            # the device coder needs a deep backlog to be worth its latency
+    in_flight = args.steps_in_flight or (4 if dev_packs else 2)
+    if not args.overlap_steps:
+        in_flight = 1
+    host_buffers = args.host_buffers or (min(B + 16, slots + 16 * coders + 32) + 64 * dev_packs)   # groups in flight + every thread's sixteen + a queue (+ the device coder's packs)
     ctx = pkg.Context(device=gpu, n_slots=slots, n_coders=coders, n_groups=max(1, min(args.groups, slots)),
                       n_host_buffers=host_buffers)
     ctx.enable_timing(True)
+    if dev_packs:
+        ctx.set_device_coder(dev_packs, args.device_min_outstanding if args.device_min_outstanding >= 0 else int(2.8 * B))
     # streams land in one pinned slab (a slot per frame: worst case seen is 1.0025 B/px) so that the
     # multi-GPU gather can stage them to HBM with plain async copies
     cap = H * W + H * W // 4 + 4096 if args.host_inputs else H * W * 3 // 4 + 4096   # SYN-1 codes to 0.53 B/px
     slab = torch.empty((B, cap), dtype=torch.uint8, pin_memory=True)
     outs = [slab[k].numpy() for k in range(B)]
     slabs, out_sets = [slab], [outs]
-    if args.overlap_steps:                                # two steps in flight: a second set of output buffers
+    for _ in range(1, in_flight):                         # several steps in flight: a set of output buffers each
         slabs.append(torch.empty((B, cap), dtype=torch.uint8, pin_memory=True))
-        out_sets.append([slabs[1][k].numpy() for k in range(B)])
+        out_sets.append([slabs[-1][k].numpy() for k in range(B)])
     shapes = [(H, W)] * B
     GATHER_CHUNK = max(1, args.gather_chunk)              # frames per exchange: bounds rank 0's receive buffers (world x 4.6 GB at 512)
     dev_pack = torch.empty(min(B, GATHER_CHUNK) * cap, dtype=torch.uint8, device=comm_dev) if world > 1 else None
@@ -290,14 +299,14 @@ def main():
                 _, lens = ctx.encode_ptrs(ptrs, shapes, not args.host_inputs, outs)
                 exchange(lens, 0)
             return
-        pending = None                                  # step k+1 is submitted before step k is collected (and exchanged)
+        pending = []                                    # up to in_flight steps are submitted before the oldest is collected (and exchanged)
         for i in range(n_steps):
-            ticket = ctx.encode_begin(ptrs, shapes, not args.host_inputs, out_sets[i & 1])
-            if pending is not None:
-                exchange(ctx.encode_end(pending[0])[1], pending[1])
-            pending = (ticket, i & 1)
-        if pending is not None:
-            exchange(ctx.encode_end(pending[0])[1], pending[1])
+            if len(pending) == in_flight:
+                t, which = pending.pop(0)
+                exchange(ctx.encode_end(t)[1], which)
+            pending.append((ctx.encode_begin(ptrs, shapes, not args.host_inputs, out_sets[i % in_flight]), i % in_flight))
+        for t, which in pending:
+            exchange(ctx.encode_end(t)[1], which)
 
     def fence():
         torch.cuda.synchronize()
@@ -322,6 +331,7 @@ def main():
     stage = ctx.stage_times()                         # summed over the group launches of the last step
     launches = max(1, ctx.last_launches())            # each kernel is launched once per group of images
     bins, coder_s = ctx.last_stats()
+    dev_stats = ctx.device_coder_stats() if dev_packs else None
     per_launch = {k: v / launches for k, v in stage.items() if k != "host_gap"}
     dom = max(per_launch, key=per_launch.get)
     imgs_per_launch = B * (args.steps if args.overlap_steps else 1) / launches   # the library's timers run over all overlapped steps
@@ -376,13 +386,13 @@ def main():
         except OSError:
             pass
         checks["every_step_same_lengths"] = all(np.array_equal(l, all_lens[0]) for l in all_lens) and len(all_lens) == args.steps
-        if args.overlap_steps and args.steps >= 2:                   # the last two steps' slabs, byte for byte
+        if args.overlap_steps and args.steps >= in_flight and in_flight >= 2 and args.warmup + args.steps >= in_flight:   # the last steps' slabs, byte for byte
             la = torch.from_numpy(np.asarray(lens)).clamp(max=cap)
             same = True
             for k in range(B):
                 n = int(la[k])
-                same = same and bool(torch.equal(slabs[0][k, :n], slabs[1][k, :n]))
-            checks["last_two_steps_identical"] = same
+                same = same and all(bool(torch.equal(slabs[0][k, :n], sl[k, :n])) for sl in slabs[1:])
+            checks[f"last_{in_flight}_steps_identical"] = same
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -406,15 +416,17 @@ def main():
             "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{B} x {H}x{W} SYN-1 gray frames per GPU per step, -n0 -e1, inputs resident in HBM" + (", steps submitted back to back (two in flight)" if args.overlap_steps else "")
+            "config": {"workload": f"{B} x {H}x{W} SYN-1 gray frames per GPU per step, -n0 -e1, inputs resident in HBM" + (f", steps submitted back to back ({in_flight} in flight)" if args.overlap_steps else "")
                        if not args.host_inputs else f"{B} x {H}x{W} SYN-1 frames per GPU per step, -n0 -e1, host inputs (PCIe-inclusive)",
-                       "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "coded_bin_buffers_in_hbm": host_buffers, "steps_overlapped": bool(args.overlap_steps),
+                       "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "coded_bin_buffers_in_hbm": host_buffers, "steps_overlapped": bool(args.overlap_steps), "steps_in_flight": in_flight,
+                       "device_coder_pack_threads": dev_packs,
                        "parallelism": f"image-per-GPU x{world}, RCCL gather of streams" if world > 1 else "single GPU",
                        "host": host_description()},
             "bit_exact": bit_exact, "bit_exact_checks": checks, "gathered_ok": gathered_ok,
             "bits_per_pixel": round(8.0 * float(np.mean(lens)) / (H * W), 4),
-            "bins_per_pixel": round(bins / (H * W * B * steps_counted), 3),
+            "bins_per_pixel": round((bins + (dev_stats["bins"] if dev_stats else 0.0)) / (H * W * B * steps_counted), 3),
             "host_coder_Mbins_per_s_per_thread": round(bins / coder_s / 1e6, 1) if coder_s > 0 else None,
+            "device_coder": dev_stats,
             # the device -> host feed of the host coder stage: 2 bytes per coded bin over PCIe (spec 63 GB/s)
             "d2h_bytes_per_bin": 2, "d2h_GB_per_s": round(bins / steps_counted * args.steps * 2 / dt / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -131,6 +131,18 @@ int nblic_amd_decode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned char
                            unsigned char *const *imgs, const size_t *img_caps, int *heights, int *widths, int *nears,
                            int *efforts, int *status);
 
+/* Opt-in: the range-coder stage (src/NBLIC.c:552-586) on the GPU as a SUPPLEMENT to the host coder threads.
+ * n_packs pack threads are started (they sleep unless there is work); each hands 64 queued images at a time to
+ * one wave of the GPU, ONE LANE PER IMAGE (~17 Mbins/s per image: a 4096^2 frame takes seconds, but 64 of them
+ * take the same seconds and none of their bins cross PCIe).  A pack is taken only when the queue of finished
+ * images holds 64 more than the host threads can take at once, and only while at least min_outstanding images
+ * of the submitted batches are unfinished -- set it to (pack latency x the host threads' image rate) so that a
+ * pack can never become the tail of the work.  The streams are byte-identical either way.  Returns the number
+ * of pack threads, or -1.  Size n_host_buffers (nblic_amd_create_ex) 64 x n_packs larger than without.       */
+int nblic_amd_set_device_coder(nblic_amd_ctx *ctx, int n_packs, int min_outstanding);
+/* What the device coder did since the context was last idle: bins coded, packs launched, images coded. */
+void nblic_amd_device_coder_stats(nblic_amd_ctx *ctx, double *bins, long *packs, long *images);
+
 /* Opt-in: raise the pixel-count limit above NBLIC_MAX_IMG_SIZE for this context (config 5 of
  * BASELINE.json exceeds the reference's own limit, src/NBLIC.h:31).  0 restores the reference limit.
  * ctx == NULL addresses the context behind the drop-in entry points of section 1.                   */

@@ -39,6 +39,7 @@ EXPORTS = (
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
     "nblic_amd_encode_batch_modes", "nblic_amd_decode_batch", "nblic_amd_serial_selftest",
     "nblic_amd_cli_main", "nblic_amd_cli_parse", "nblic_amd_read_gray", "nblic_amd_write_gray",
+    "nblic_amd_set_device_coder", "nblic_amd_device_coder_stats",
     "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_range_code_chunked", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
 )
 
@@ -108,6 +109,10 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_read_gray.argtypes = [C.c_char_p, _u8p, C.c_size_t, ip, ip]
     lib.nblic_amd_write_gray.restype = C.c_int
     lib.nblic_amd_write_gray.argtypes = [C.c_char_p, _u8p, C.c_int, C.c_int, C.c_int]
+    lib.nblic_amd_set_device_coder.restype = C.c_int
+    lib.nblic_amd_set_device_coder.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.nblic_amd_device_coder_stats.restype = None
+    lib.nblic_amd_device_coder_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]
     lib.nblic_amd_set_max_pixels.restype = None
     lib.nblic_amd_set_max_pixels.argtypes = [C.c_void_p, C.c_long]
     lib.nblic_amd_enable_timing.restype = None
@@ -333,6 +338,15 @@ class Context:
 
     def selftest(self) -> int:
         return self.lib.nblic_amd_selftest(self.handle)
+
+    def set_device_coder(self, n_packs: int, min_outstanding: int = 0) -> int:
+        """Range-coder stage on the GPU for part of the backlog (``nblic_amd_set_device_coder``)."""
+        return int(self.lib.nblic_amd_set_device_coder(self.handle, n_packs, min_outstanding))
+
+    def device_coder_stats(self) -> dict:
+        b, p, i = C.c_double(), C.c_long(), C.c_long()
+        self.lib.nblic_amd_device_coder_stats(self.handle, C.byref(b), C.byref(p), C.byref(i))
+        return {"bins": b.value, "packs": p.value, "images": i.value}
 
     def serial_selftest(self) -> int:
         return self.lib.nblic_amd_serial_selftest(self.handle)

@@ -26,6 +26,7 @@
 #include <sys/mman.h>
 
 #include "../../include/nblic_amd.h"
+#include "device_coder.h"
 #include "kernels_e1.h"
 #include "model.h"
 #include "range_coder.h"
@@ -246,6 +247,10 @@ struct nblic_amd_ctx {
     double wait_s = 0;                    // of coder_s: waiting for bins to arrive from HBM
     long takes[kMaxTake + 1] = {0};       // how many times a thread took k images together
     std::mutex stat_m;
+    // device coder (device_coder.hip): pack threads that hand 64 queued images at a time to one wave each
+    std::vector<std::thread> dev_coders;
+    int dev_min_outstanding = 0;          // a pack is taken only while at least this many images of the submitted batches are unfinished
+    double dev_bins = 0; long dev_packs = 0, dev_images = 0;
     // decode batches (nblic_amd_decode_batch): a stream of their own and grow-only device / pinned arenas
     hipStream_t dec_stream = nullptr;
     uint8_t *dec_arena = nullptr; size_t dec_arena_cap = 0;
@@ -631,6 +636,93 @@ static void coder_main(nblic_amd_ctx *c, int index) {
     t.destroy();
 }
 
+// ---- device coder pack threads -----------------------------------------------------------------
+// A pack thread waits until the queue holds a full pack BEYOND what the host coder threads can take
+// at once (they keep priority: a host core codes an image forty times faster than a lane) and until
+// enough work is outstanding that the pack's latency (seconds) cannot become the tail of the batch;
+// then it hands up to 64 images to one wave, sleeps in a blocking stream wait, copies the coder bytes
+// to the callers' buffers and completes the images exactly as a host coder thread does.
+constexpr int kDevPack = 64;
+
+static int dev_take(const nblic_amd_ctx *c) {                  // call with c->rm held
+    const size_t q = c->ready.size();
+    const size_t reserve = c->simd ? c->coders.size() * size_t(kMaxTake) / 2 : c->coders.size();
+    if (q < size_t(kDevPack) + reserve) return 0;
+    if (int(q) + c->batch_to_come < c->dev_min_outstanding) return 0;
+    for (size_t k = 0; k < size_t(kDevPack); k++) if (c->ready[q - 1 - k].kind == 1) return 0;   // QNBLIC images are host work
+    return kDevPack;
+}
+
+static void dev_coder_main(nblic_amd_ctx *c, int index) {
+    (void)index;
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;
+    RcJob *h_jobs = nullptr, *d_jobs = nullptr;
+    uint32_t *h_lens = nullptr, *d_lens = nullptr;
+    uint8_t *d_out = nullptr; size_t out_cap = 0;
+    bool ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&done, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess &&
+              hipHostMalloc((void **)&h_jobs, kDevPack * sizeof(RcJob), hipHostMallocDefault) == hipSuccess &&
+              hipMalloc((void **)&d_jobs, kDevPack * sizeof(RcJob)) == hipSuccess &&
+              hipHostMalloc((void **)&h_lens, kDevPack * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
+              hipMalloc((void **)&d_lens, kDevPack * sizeof(uint32_t)) == hipSuccess;
+    if (!ok) c->failed = true;
+    for (;;) {
+        ReadyImage im[kDevPack];
+        int take = 0;
+        {
+            std::unique_lock<std::mutex> l(c->rm);
+            c->rcv.wait(l, [c] { return c->stop || dev_take(c) > 0; });
+            if (c->stop) break;
+            take = dev_take(c);
+            for (int k = 0; k < take; k++) { im[k] = c->ready.back(); c->ready.pop_back(); }   // the NEWEST images: the oldest are the host threads' next packs
+        }
+        if (take == 0) continue;
+        // output slots on the device: worst case seen is 1.0025 B/px + 20
+        size_t need = 0, off[kDevPack];
+        for (int k = 0; k < take; k++) { off[k] = need; need += (size_t(im[k].h) * size_t(im[k].w) * 9 / 8 + 4096 + 255) & ~size_t(255); }
+        bool good = ok;
+        if (good && need > out_cap) { hipFree(d_out); d_out = nullptr; out_cap = 0; good = hipMalloc((void **)&d_out, need) == hipSuccess; if (good) out_cap = need; }
+        double bins = 0;
+        for (int k = 0; k < take && good; k++) {
+            const size_t cap_user = im[k].caps[im[k].job] < (size_t(1) << 40) ? im[k].caps[im[k].job] : (size_t(1) << 40);
+            const size_t cap_dev = (k + 1 < take ? off[k + 1] : need) - off[k];
+            const size_t cap = cap_user > size_t(kHeaderBytes) ? (cap_user - kHeaderBytes < cap_dev ? cap_user - kHeaderBytes : cap_dev) : 0;
+            h_jobs[k] = RcJob{c->cbufs[size_t(im[k].cb)].p, d_out + off[k], d_lens + k, im[k].n_ev, uint32_t(cap < 0xFFFFFFF0u ? cap : 0xFFFFFFF0u)};
+            bins += double(im[k].n_ev);
+        }
+        good = good && hipMemcpyAsync(d_jobs, h_jobs, size_t(take) * sizeof(RcJob), hipMemcpyHostToDevice, st) == hipSuccess &&
+               device_range_code(d_jobs, take, st) &&
+               hipMemcpyAsync(h_lens, d_lens, size_t(take) * sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipEventRecord(done, st) == hipSuccess && hipEventSynchronize(done) == hipSuccess;
+        for (int k = 0; k < take; k++) {
+            long len = -1;
+            if (good && h_lens[k] != 0xFFFFFFFFu) {
+                unsigned char *dst = im[k].outs[im[k].job];
+                write_header(dst, im[k].h, im[k].w, im[k].near, im[k].k_step, im[k].effort);
+                if (hipMemcpyAsync(dst + kHeaderBytes, d_out + off[k], h_lens[k], hipMemcpyDeviceToHost, st) == hipSuccess) len = long(kHeaderBytes) + long(h_lens[k]);
+            } else if (good) {
+                fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", im[k].job, im[k].caps[im[k].job]);
+            }
+            im[k].lens[im[k].job] = len;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) good = false;
+        if (!good) { c->failed = true; for (int k = 0; k < take; k++) im[k].lens[im[k].job] = -1; }
+        { std::lock_guard<std::mutex> l(c->stat_m); c->dev_bins += bins; c->dev_packs++; c->dev_images += take; }
+        {
+            std::lock_guard<std::mutex> l(c->fm);
+            for (int k = 0; k < take; k++) { c->free_cbufs.push_back(im[k].cb); if (im[k].batch) im[k].batch->remaining -= 1; }
+            c->coding -= take;
+        }
+        c->fcv.notify_all();
+    }
+    hipFree(d_out); hipFree(d_jobs); hipFree(d_lens);
+    if (h_jobs) hipHostFree(h_jobs);
+    if (h_lens) hipHostFree(h_lens);
+    if (done) hipEventDestroy(done);
+    if (st) hipStreamDestroy(st);
+}
+
 // Takes a coded-bin buffer of at least `words` for slot s (waits for one if the coder threads are
 // behind: that is the pipeline's back-pressure).
 static bool acquire_coded(nblic_amd_ctx *c, Slot &s, size_t words) {
@@ -763,6 +855,7 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
         for (auto &v : c->stage_ms) v = 0;
         c->stage_launches = 0;
         c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; for (auto &v : c->takes) v = 0;
+        c->dev_bins = 0; c->dev_packs = 0; c->dev_images = 0;
         c->failed = false;
         c->t_batch = std::chrono::steady_clock::now();
         c->trace = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 64);
@@ -1175,6 +1268,7 @@ void nblic_amd_destroy(nblic_amd_ctx *c) {
     { std::lock_guard<std::mutex> l(c->rm); c->stop = true; }
     c->rcv.notify_all();
     for (auto &t : c->coders) t.join();
+    for (auto &t : c->dev_coders) t.join();
     { std::lock_guard<std::mutex> l(c->dm); c->stop_drivers = true; }
     c->dcv.notify_all();
     for (auto &t : c->drivers) t.join();
@@ -1280,6 +1374,21 @@ int nblic_amd_decode_batch(nblic_amd_ctx *c, int n_images, const unsigned char *
     if (!decode_batch(c, n_images, streams, stream_lens, imgs, img_caps, heights, widths, nears, efforts, status)) return -1;
     for (int k = 0; k < n_images; k++) if (status[k] != 0) return -1;
     return 0;
+}
+
+int nblic_amd_set_device_coder(nblic_amd_ctx *c, int n_packs, int min_outstanding) {
+    if (!c || n_packs < 0 || n_packs > 64) return -1;
+    std::lock_guard<std::mutex> g(c->api);
+    { std::lock_guard<std::mutex> l(c->rm); c->dev_min_outstanding = min_outstanding > 0 ? min_outstanding : 0; }
+    while (int(c->dev_coders.size()) < n_packs) c->dev_coders.emplace_back(dev_coder_main, c, int(c->dev_coders.size()));
+    return int(c->dev_coders.size());
+}
+
+void nblic_amd_device_coder_stats(nblic_amd_ctx *c, double *bins, long *packs, long *images) {
+    std::lock_guard<std::mutex> l(c->stat_m);
+    if (bins) *bins = c->dev_bins;
+    if (packs) *packs = c->dev_packs;
+    if (images) *images = c->dev_images;
 }
 
 int nblic_amd_serial_selftest(nblic_amd_ctx *c) {

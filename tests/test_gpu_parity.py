@@ -464,3 +464,28 @@ def test_soak_random_contexts_and_batches(pkg, oracle):
                 assert ctx.qencode_batch(q) == [oracle.qencode(i) for i in q], rnd
         finally:
             ctx.close()
+
+
+def test_device_coder_supplements_host_threads(pkg, oracle):
+    """The range-coder stage on the GPU (one lane per image, 64 images per wave) next to ONE host coder
+    thread: with a deep queue of finished images the pack threads take the newest 64 at a time.  Every
+    stream -- host-coded or device-coded, all sizes and contents, images that end at very different bins
+    inside one wave, an output buffer that is too small -- must be the oracle's, byte for byte."""
+    rng = np.random.default_rng(41)
+    imgs = []
+    for k in range(420):
+        h, w = int(rng.integers(1, 150)), int(rng.integers(1, 200))
+        imgs.append(inputs.make(inputs.CONTENTS[k % len(inputs.CONTENTS)], h, w) if k % 3 else inputs.syn1(h, w, seed=k + 1))
+    imgs[7] = inputs.syn1(700, 900, seed=5)                        # one long stream among short ones
+    want = [oracle.encode(i, 0, 1)[0] for i in imgs]
+    ctx = pkg.Context(device=0, n_slots=128, n_coders=1, n_groups=2, n_host_buffers=480)
+    try:
+        assert ctx.set_device_coder(2, 0) == 2
+        got = ctx.encode_batch(imgs)
+        stats = ctx.device_coder_stats()
+        modes = ctx.encode_modes(imgs[:200], [2] * 200, [1] * 200)[0]      # serial-mode images go through the same queue
+    finally:
+        ctx.close()
+    assert got == want
+    assert modes == [oracle.encode(i, 2, 1)[0] for i in imgs[:200]]
+    assert stats["images"] >= 64 and stats["packs"] >= 1, stats           # the device coder did take part
