@@ -170,7 +170,8 @@ def main():
                     help="collect every step before submitting the next (default: step k+1 is submitted with nblic_amd_encode_batch_begin "
                          "before step k is collected, as a continuous feed would; the pipeline's fill and drain are then paid once per "
                          "run of steps, inside the timed region, instead of once per step)")
-    ap.add_argument("--device-packs", type=int, default=6, help="pack threads of the device range coder (64 images per wave, one lane per image), a supplement to the host coder threads; 0 = host threads only")
+    ap.add_argument("--device-packs", type=int, default=0, help="pack threads of the device range coder (64 images per wave, one lane per image), a supplement to the host coder threads; 0 = host threads only "
+                                                                 "(default: measured on MI355X a lane codes ~7 Mbins/s, a pack of 64 4096^2 frames takes ~11 s and its kernel stalls the streams that share its hardware queue: 5.4 -> 2.9 Gpx/s with one pack, DESIGN.md section 4)")
     ap.add_argument("--steps-in-flight", type=int, default=0, help="steps submitted ahead of the one being collected (0 = 4 with the device coder, else 2)")
     ap.add_argument("--device-min-outstanding", type=int, default=-1, help="images that must be unfinished for the device coder to take a pack (-1 = 2.8 x batch: its seconds of latency never become the tail of the run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -146,7 +146,7 @@ constexpr int kMaxTake = 16;                                       // images one
 
 }  // namespace nblic
 // One submitted batch (nblic_amd_encode_batch_begin .. _end); `remaining` is guarded by ctx->fm.
-struct nblic_amd_batch { int remaining = 0; int n_images = 0; long *lens = nullptr; bool ok = true; };
+struct nblic_amd_batch { int remaining = 0; int n_images = 0; long *lens = nullptr; bool ok = true; bool submitted = false; };   // submitted: every image has been handed to a group (guarded by ctx->fm)
 namespace nblic {
 
 struct ReadyImage {                                                  // everything a coder thread needs
@@ -247,6 +247,18 @@ struct nblic_amd_ctx {
     double wait_s = 0;                    // of coder_s: waiting for bins to arrive from HBM
     long takes[kMaxTake + 1] = {0};       // how many times a thread took k images together
     std::mutex stat_m;
+    // Submission is asynchronous: _begin only queues the batch; the submitter thread hands its images to the groups
+    // (which blocks while every group is busy), so a caller can keep several batches ahead of the pipeline.
+    struct SubmitItem {
+        ::nblic_amd_batch *b; int n; const uint8_t *const *imgs; bool on_device; const int *hs, *ws;
+        uint8_t *const *outs; const size_t *caps; long *lens; const int *nears, *efforts; unsigned char *const *recons;
+    };
+    std::thread submitter;
+    std::mutex sm;
+    std::condition_variable scv;
+    std::deque<SubmitItem> sq;
+    bool stop_submit = false;
+    int queued_images = 0;                // images of batches still waiting in sq (guarded by rm, like batch_to_come)
     // device coder (device_coder.hip): pack threads that hand 64 queued images at a time to one wave each
     std::vector<std::thread> dev_coders;
     int dev_min_outstanding = 0;          // a pack is taken only while at least this many images of the submitted batches are unfinished
@@ -648,7 +660,7 @@ static int dev_take(const nblic_amd_ctx *c) {                  // call with c->r
     const size_t q = c->ready.size();
     const size_t reserve = c->simd ? c->coders.size() * size_t(kMaxTake) / 2 : c->coders.size();
     if (q < size_t(kDevPack) + reserve) return 0;
-    if (int(q) + c->batch_to_come < c->dev_min_outstanding) return 0;
+    if (int(q) + c->batch_to_come + c->queued_images < c->dev_min_outstanding) return 0;
     for (size_t k = 0; k < size_t(kDevPack); k++) if (c->ready[q - 1 - k].kind == 1) return 0;   // QNBLIC images are host work
     return kDevPack;
 }
@@ -904,6 +916,33 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
     }
 }
 
+static void submitter_main(nblic_amd_ctx *c) {
+    if (hipSetDevice(c->device) != hipSuccess) c->failed = true;
+    for (;;) {
+        nblic_amd_ctx::SubmitItem it;
+        {
+            std::unique_lock<std::mutex> l(c->sm);
+            c->scv.wait(l, [c] { return c->stop_submit || !c->sq.empty(); });
+            if (c->sq.empty()) return;
+            it = c->sq.front(); c->sq.pop_front();
+        }
+        {
+            std::lock_guard<std::mutex> g(c->api);
+            { std::lock_guard<std::mutex> l(c->rm); c->queued_images -= it.n; }         // from here on they are counted in batch_to_come
+            encode_submit(c, it.b, it.n, it.imgs, it.on_device, it.hs, it.ws, it.outs, it.caps, it.lens, it.nears, it.efforts, it.recons);
+        }
+        { std::lock_guard<std::mutex> l(c->fm); it.b->submitted = true; }
+        c->fcv.notify_all();
+    }
+}
+
+static void queue_batch(nblic_amd_ctx *c, const nblic_amd_ctx::SubmitItem &it) {
+    for (int k = 0; k < it.n; k++) it.lens[k] = -1;
+    { std::lock_guard<std::mutex> l(c->rm); c->queued_images += it.n; }
+    { std::lock_guard<std::mutex> l(c->sm); c->sq.push_back(it); }
+    c->scv.notify_all();
+}
+
 static void report_coders(nblic_amd_ctx *c) {                        // NBLIC_AMD_DBG & 32, when nothing is outstanding
     bool idle;
     { std::lock_guard<std::mutex> l(c->fm); idle = c->coding == 0; }
@@ -919,7 +958,7 @@ static void report_coders(nblic_amd_ctx *c) {                        // NBLIC_AM
 static bool encode_wait(nblic_amd_ctx *c, nblic_amd_batch *b) {
     {   // wait for the coder threads (and with them every group's GPU work) of THIS batch
         std::unique_lock<std::mutex> l(c->fm);
-        c->fcv.wait(l, [b] { return b->remaining == 0; });
+        c->fcv.wait(l, [b] { return b->submitted && b->remaining == 0; });
     }
     bool ok = b->ok;
     for (int k = 0; k < b->n_images; k++) if (b->lens[k] < 0) ok = false;
@@ -930,7 +969,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
                          const int *ws, uint8_t *const *outs, const size_t *caps, long *lens) {
     if (hipSetDevice(c->device) != hipSuccess) return false;
     nblic_amd_batch b;
-    { std::lock_guard<std::mutex> g(c->api); encode_submit(c, &b, n_images, imgs, on_device, hs, ws, outs, caps, lens); }
+    queue_batch(c, nblic_amd_ctx::SubmitItem{&b, n_images, imgs, on_device, hs, ws, outs, caps, lens, nullptr, nullptr, nullptr});
     bool ok = encode_wait(c, &b);
     bool idle;
     { std::lock_guard<std::mutex> l(c->fm); idle = c->coding == 0; }
@@ -1251,6 +1290,7 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
         if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { cs = nullptr; nblic_amd_destroy(c); return nullptr; }
     for (int i = 0; i < n_coders; i++) c->coders.emplace_back(coder_main, c, i);
     for (int i = 0; i < n_groups; i++) c->drivers.emplace_back(driver_main, c, i);
+    c->submitter = std::thread(submitter_main, c);
     return c;
 }
 
@@ -1265,6 +1305,9 @@ nblic_amd_ctx *nblic_amd_create(int device, int n_slots, int n_coders) {
 void nblic_amd_destroy(nblic_amd_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    { std::lock_guard<std::mutex> l(c->sm); c->stop_submit = true; }
+    c->scv.notify_all();
+    if (c->submitter.joinable()) c->submitter.join();
     { std::lock_guard<std::mutex> l(c->rm); c->stop = true; }
     c->rcv.notify_all();
     for (auto &t : c->coders) t.join();
@@ -1311,8 +1354,7 @@ nblic_amd_batch *nblic_amd_encode_batch_begin(nblic_amd_ctx *c, int n_images, co
                                               const size_t *out_caps, long *out_lens) {
     if (!c || n_images < 0 || hipSetDevice(c->device) != hipSuccess) return nullptr;
     auto *b = new nblic_amd_batch;
-    std::lock_guard<std::mutex> g(c->api);
-    encode_submit(c, b, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps, out_lens);
+    queue_batch(c, nblic_amd_ctx::SubmitItem{b, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps, out_lens, nullptr, nullptr, nullptr});
     return b;
 }
 
@@ -1361,7 +1403,7 @@ int nblic_amd_encode_batch_modes(nblic_amd_ctx *c, int n_images, const unsigned 
                                  unsigned char *const *outs, const size_t *out_caps, long *out_lens, unsigned char *const *recons) {
     if (!c || n_images < 0 || hipSetDevice(c->device) != hipSuccess) return -1;
     nblic_amd_batch b;
-    { std::lock_guard<std::mutex> g(c->api); encode_submit(c, &b, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps, out_lens, nears, efforts, recons); }
+    queue_batch(c, nblic_amd_ctx::SubmitItem{&b, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps, out_lens, nears, efforts, recons});
     const bool ok = encode_wait(c, &b);
     return ok && !c->failed ? 0 : -1;
 }

@@ -31,6 +31,7 @@ CASES = [
     (64, 16384, 0, 3, 1), (24, 16384, 2, 2, 1), (16, 16385, 0, 3, 1), (3, 20000, 0, 1, 1), (3, 20000, 2, 2, 1), (3, 20000, 1, 3, 1),
     (8, 16384, 3, 1, 1), (6, 16385, 2, 1, 1),
     (512, 512, 0, 2, 1), (512, 512, 0, 3, 1), (512, 512, 2, 2, 1), (512, 512, 1, 3, 1),
+    (1024, 16384, 0, 3, 1),           # a 1/16 band of config 5's frame (same width, same mode)
     (8192, 8192, 2, 2, 1),            # BASELINE config 4
     (16384, 16384, 0, 3, 1),          # BASELINE config 5 (needs the raised limit)
 ]
