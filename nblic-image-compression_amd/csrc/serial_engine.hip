@@ -576,13 +576,17 @@ __device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const S
             const int v = S.ctx[adr];
             const int sign = bias_sign(v), px = bias_apply(v, px0);
             const int mk = px * 2 + sign;
+            int bins_px = 0;
             const int z = walk_symbol_t(k_step, ktab, L.qu, L.qv, -1, [&](int qu, int qv, int node, int) {       // NBLIC.c:628-637, :552-573
                 const uint32_t cu = S.cnt[qu][node], cv = S.cnt[qv][node];
                 const int u0 = int(cu & 0xFFFFu), u1 = int(cu >> 16);
                 const int v0 = int(cv & 0xFFFFu), v1 = int(cv >> 16);
                 const int prob = mix_prob(prob_one(u0, u1), prob_one(v0, v1), L.qw);
                 const uint32_t cut = lo + uint32_t((u64(hi - lo) * uint32_t(prob)) >> 12);
-                const int bin = sw.overrun ? 0 : int(window <= cut);     // past the end of the stream every symbol ends at once (a truncated stream must not spin)
+                // a symbol of a valid stream has well under a hundred bins; a damaged one (all ones) could walk for ever:
+                // from the 512th bin of a pixel on, and past the end of the stream, every symbol ends at once
+                if (++bins_px > 512) sw.overrun = true;
+                const int bin = sw.overrun ? 0 : int(window <= cut);
                 if (bin) hi = cut; else lo = cut + 1;
                 while (((lo ^ hi) >> 24) == 0) { window = (window << 8) | sw.next(); lo <<= 8; hi = (hi << 8) | 0xFFu; }
                 Counter a{u0, u1};

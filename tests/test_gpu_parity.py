@@ -489,3 +489,49 @@ def test_device_coder_supplements_host_threads(pkg, oracle):
     assert got == want
     assert modes == [oracle.encode(i, 2, 1)[0] for i in imgs[:200]]
     assert stats["images"] >= 64 and stats["packs"] >= 1, stats           # the device coder did take part
+
+
+def test_serial_paths_at_extreme_widths_and_bad_streams(pkg, oracle):
+    """Rows wider than the LDS row ring (taps then come from the reconstruction in memory): the encoder's
+    model stage beyond ~50,000 columns, the decoders beyond ~24,000, up to the format's 65,535; device-resident
+    inputs for the serial modes; and truncated / corrupt streams, which must come back as failures, never hang."""
+    torch = pytest.importorskip("torch")
+    cases = [(inputs.syn1(2, 65535, 3), 2, 1), (inputs.syn1(3, 52000, 4), 0, 2), (inputs.syn1(2, 30000, 5), 1, 3),
+             (inputs.syn1(1, 65535, 6), 9, 1), (inputs.syn1(40, 700, 7), 3, 2)]
+    ctx = pkg.Context(device=0, n_slots=8, n_coders=2, n_groups=2, n_host_buffers=16)
+    try:
+        streams, recs = ctx.encode_modes([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+        for (img, near, effort), s, rec in zip(cases, streams, recs):
+            ws, wrec, *_ = oracle.encode(img, near, effort)
+            assert s == ws and np.array_equal(rec, wrec), (img.shape, near, effort)
+        q = ctx.qencode_batch([inputs.syn1(3, 40000, 8), inputs.syn1(2, 65535, 9)])
+        dec = ctx.decode_batch(streams + q)
+        for (img, near, effort), d, rec in zip(cases, dec, recs):
+            assert d is not None and np.array_equal(d[0], rec) and d[1:] == (near, effort), img.shape
+        assert np.array_equal(dec[-2][0], inputs.syn1(3, 40000, 8)) and np.array_equal(dec[-1][0], inputs.syn1(2, 65535, 9))
+        # device-resident planes through the any-mode entry point
+        import ctypes as C
+        dev = [torch.from_numpy(c[0]).cuda() for c in cases[2:]]
+        torch.cuda.synchronize()
+        k = len(dev)
+        outs = [np.empty(pkg.out_capacity(*c[0].shape), np.uint8) for c in cases[2:]]
+        rr = [np.empty_like(c[0]) for c in cases[2:]]
+        lens = (C.c_long * k)()
+        rc = ctx.lib.nblic_amd_encode_batch_modes(
+            ctx.handle, k, (C.c_void_p * k)(*[d.data_ptr() for d in dev]), 1,
+            (C.c_int * k)(*[c[0].shape[0] for c in cases[2:]]), (C.c_int * k)(*[c[0].shape[1] for c in cases[2:]]),
+            (C.c_int * k)(*[c[1] for c in cases[2:]]), (C.c_int * k)(*[c[2] for c in cases[2:]]),
+            (C.c_void_p * k)(*[o.ctypes.data for o in outs]), (C.c_size_t * k)(*[o.size for o in outs]), lens,
+            (C.c_void_p * k)(*[r.ctypes.data for r in rr]))
+        assert rc == 0
+        for j in range(k):
+            assert outs[j][: lens[j]].tobytes() == streams[2 + j] and np.array_equal(rr[j], recs[2 + j])
+        # damaged input
+        good = streams[4]
+        bad = [good[: len(good) * 6 // 10], good[:16], good[:20] + bytes(len(good) - 20), b"NBLIC0.3" + bytes(8),
+               q[0][: len(q[0]) // 2], q[0][:8]]
+        res = ctx.decode_batch(bad)
+        assert res[0] is None and res[1] is None and res[3] is None and res[4] is None and res[5] is None
+        assert res[2] is None or res[2][0].shape == (40, 700)          # zeros after the header may decode to SOMETHING, but must not hang
+    finally:
+        ctx.close()
