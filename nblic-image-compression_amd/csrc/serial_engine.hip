@@ -29,7 +29,11 @@ namespace nblic {
 typedef long long i64;
 typedef unsigned long long u64;
 
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }     // one wave per block: orders LDS traffic between lanes
+// One wave per block: "synchronising" means that this wave's LDS operations have completed (the lanes run in lock-step)
+// and that the compiler moves no memory access across the point.  A __syncthreads() would also wait for every global
+// load and store in flight (vmcnt(0)) -- the statistics prefetched for the next pixel, the stores of this one -- four
+// times per pixel.
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Pointers read out of the job record are generic to the compiler; telling it they are global memory
 // turns flat_load / flat_store into global_load / global_store and keeps LDS out of their waits.
@@ -466,7 +470,7 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
             const int xr = symbol_to_pixel(y, px, sign, np);
             err = clip_err(xr, px0);
             S.ctx[adr] = bias_update(v, err);
-            if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else recon[row_at + j] = uint8_t(xr);
+            if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else { recon[row_at + j] = uint8_t(xr); __threadfence_block(); }
             S.rec_ring[j & 63] = pack_s1(px0, adr, L);
             S.pxs_ring[j & 63] = uint16_t(px | (sign << 8));
             if ((j & 63) == 63 || j == w - 1) {                          // a lane per record: coalesced stores
@@ -616,7 +620,7 @@ __device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const S
             const int xr = symbol_to_pixel(y, px, sign, np);
             err = clip_err(xr, px0);
             S.ctx[adr] = bias_update(v, err);
-            if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else out[row_at + j] = uint8_t(xr);
+            if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else { out[row_at + j] = uint8_t(xr); __threadfence_block(); }
             if constexpr (N > 0) {
                 if (lane == 0) S.q.vn8[15] = int8_t(xr - kMid);
                 wave_sync();
@@ -718,7 +722,7 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restri
             const int px_out = symbol_to_pixel(y, px, sign, 0);
             err = px_out - px0;
             S.ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
-            if (cached) { r0[j] = uint8_t(px_out); if (windowed) tw.advance(r1, r2, w, j, px_out); } else out[row_at + j] = uint8_t(px_out);
+            if (cached) { r0[j] = uint8_t(px_out); if (windowed) tw.advance(r1, r2, w, j, px_out); } else { out[row_at + j] = uint8_t(px_out); __threadfence_block(); }
             if (sw.overrun) break;
         }
         if (cached) {

@@ -491,7 +491,7 @@ def test_device_coder_supplements_host_threads(pkg, oracle):
     assert stats["images"] >= 64 and stats["packs"] >= 1, stats           # the device coder did take part
 
 
-def test_serial_paths_at_extreme_widths_and_bad_streams(pkg, oracle):
+def test_serial_paths_at_extreme_widths_and_bad_streams(gpu_ctx, pkg, oracle):      # gpu_ctx first: torch must initialise HIP before the library does
     """Rows wider than the LDS row ring (taps then come from the reconstruction in memory): the encoder's
     model stage beyond ~50,000 columns, the decoders beyond ~24,000, up to the format's 65,535; device-resident
     inputs for the serial modes; and truncated / corrupt streams, which must come back as failures, never hang."""
