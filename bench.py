@@ -368,12 +368,25 @@ def main():
             d1 = min(timed_call(lambda: ctx.encode_ptrs(ptrs[:1], shapes[:1], not args.host_inputs, outs[:1])) for _ in range(3))
             extra["single_frame_ms"] = round(d1 * 1e3, 2)
             if not args.host_inputs:                                 # SURVEY 8(d)'s quantity: every frame uploaded over PCIe inside the region
-                nb = min(B, 128)
-                host = [pkg.syn1(H, W, seed=rank * B + k + 1) for k in range(nb)]
-                dh = timed_call(lambda: ctx.encode_ptrs([f.ctypes.data for f in host], shapes[:nb], False, outs[:nb]))
-                extra["pcie_inclusive_Mpixel_per_s"] = round(nb * H * W / dh / 1e6, 2)
-                extra["pcie_inclusive_frames"] = nb
-                del host
+                # the same B frames in PINNED host memory (SURVEY allows it), two steps back to back like the headline
+                hslab = torch.empty((B, H * W), dtype=torch.uint8, pin_memory=True)
+                hrows = [hslab[k].numpy() for k in range(B)]
+                with ThreadPoolExecutor(max_workers=max(1, min(16, cpus))) as ex:
+                    list(ex.map(lambda k: np.copyto(hrows[k], pkg.syn1(H, W, seed=rank * B + k + 1).reshape(-1)), range(B)))
+                hptrs = [r.ctypes.data for r in hrows]
+
+                def two_steps():
+                    t1 = ctx.encode_begin(hptrs, shapes, False, out_sets[0])
+                    t2 = ctx.encode_begin(hptrs, shapes, False, out_sets[1 % len(out_sets)]) if len(out_sets) > 1 else None
+                    ctx.encode_end(t1)
+                    if t2 is not None:
+                        ctx.encode_end(t2)
+                n_steps_h = 2 if len(out_sets) > 1 else 1
+                dh = timed_call(two_steps)
+                extra["pcie_inclusive_Mpixel_per_s"] = round(n_steps_h * B * H * W / dh / 1e6, 2)
+                extra["pcie_inclusive_frames"] = n_steps_h * B
+                extra["pcie_inclusive_note"] = "frames in pinned host memory, uploaded inside the timed region; includes the pipeline's fill and drain once"
+                del hslab, hrows
 
     # ---- correctness of what was timed (outside the timed region) ------------------------------------
     bit_exact, checks = None, {}

@@ -1285,7 +1285,9 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
         const size_t v = size_t(atol(cb)) & ~size_t(3);          // a multiple of four: the rows hold four bins per word
         if (v >= 4096 && v <= kChunkBins) c->chunk_bins = v;
     }
-    c->copy_streams.resize(size_t(n_coders < kCopyStreams ? n_coders : kCopyStreams));
+    int n_copy = n_coders < kCopyStreams ? n_coders : kCopyStreams;
+    if (const char *cs = getenv("NBLIC_AMD_COPY_STREAMS")) { const int v = atoi(cs); if (v >= 1 && v <= 32) n_copy = v; }   // experiments with the copy engines
+    c->copy_streams.resize(size_t(n_copy));
     for (auto &cs : c->copy_streams)
         if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { cs = nullptr; nblic_amd_destroy(c); return nullptr; }
     for (int i = 0; i < n_coders; i++) c->coders.emplace_back(coder_main, c, i);
