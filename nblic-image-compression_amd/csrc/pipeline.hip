@@ -516,8 +516,17 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
                 longest = len > longest ? len : longest;
             }
             const uint32_t n_rows = uint32_t((longest + 3) / 4);
+            // NBLIC_AMD_DIRECT_ROWS=<blocks> (experiment): the interleave kernel, on a SMALL grid, stores the rows straight into
+            // the mapped host ring -- no staging pass in HBM, no runtime copy (which this runtime performs with a blit kernel
+            // on a chip-wide grid); a few workgroups keep enough bytes in flight to fill the link
+            static const int direct_blocks = getenv("NBLIC_AMD_DIRECT_ROWS") ? atoi(getenv("NBLIC_AMD_DIRECT_ROWS")) : 0;
+            uint64_t *mapped = nullptr;
+            if (direct_blocks > 0 && n_rows && hipHostGetDevicePointer((void **)&mapped, t.rows(c), 0) != hipSuccess) mapped = nullptr;
             uint64_t *d = t.dev_rows(c);
-            if (n_rows) {
+            if (n_rows && mapped) {
+                hipLaunchKernelGGL(k_interleave16, dim3(unsigned(direct_blocks)), dim3(256), 0, t.stream, a, mapped, n_rows);
+                HIP_OK(hipGetLastError());
+            } else if (n_rows) {
                 hipLaunchKernelGGL(k_interleave16, dim3((n_rows * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_rows);
                 HIP_OK(hipGetLastError());
                 HIP_OK(hipMemcpyAsync(t.rows(c), d, size_t(n_rows) * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));

@@ -33,8 +33,10 @@ def build(force: bool = False) -> None:
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True, capture_output=True)
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(os.path.join(_HERE, "_ref", "libnblic_ref.so"))):
-        subprocess.run(["make", "-C", _HERE, "ref"], check=True, capture_output=True)
+    if os.path.isdir("/root/reference/src"):
+        for target, name in (("ref", "libnblic_ref.so"), ("ref_big", "libnblic_ref_big.so")):       # ref_big: config 5's raised pixel limit
+            if force or not os.path.exists(os.path.join(_HERE, "_ref", name)):
+                subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
 
 
 def syn1(h: int, w: int, seed: int = 1) -> np.ndarray:

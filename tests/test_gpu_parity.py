@@ -535,3 +535,22 @@ def test_serial_paths_at_extreme_widths_and_bad_streams(gpu_ctx, pkg, oracle):  
         assert res[2] is None or res[2][0].shape == (40, 700)          # zeros after the header may decode to SOMETHING, but must not hang
     finally:
         ctx.close()
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """`bench.py --gpus 2` started directly: the launcher starts two ranks (both on GPU 0 here, gloo for the
+    collectives), each encodes its own batch, the streams are gathered on rank 0; the line must say n_gpus 2,
+    gathered_ok and bit_exact."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["NBLIC_BENCH_DEVICE"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--height", "512", "--width", "512",
+                        "--batch", "24", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["gathered_ok"] is True and line["bit_exact"] is True, line
+    assert line["batch8_frames_per_gpu"] == 4
