@@ -516,19 +516,16 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
                 longest = len > longest ? len : longest;
             }
             const uint32_t n_rows = uint32_t((longest + 3) / 4);
-            // NBLIC_AMD_DIRECT_ROWS=<blocks> (experiment): the interleave kernel, on a SMALL grid, stores the rows straight into
-            // the mapped host ring -- no staging pass in HBM, no runtime copy (which this runtime performs with a blit kernel
-            // on a chip-wide grid); a few workgroups keep enough bytes in flight to fill the link
-            static const int direct_blocks = getenv("NBLIC_AMD_DIRECT_ROWS") ? atoi(getenv("NBLIC_AMD_DIRECT_ROWS")) : 0;
-            uint64_t *mapped = nullptr;
-            if (direct_blocks > 0 && n_rows && hipHostGetDevicePointer((void **)&mapped, t.rows(c), 0) != hipSuccess) mapped = nullptr;
+            // (Measured and rejected, twice: letting this kernel store straight into the mapped host ring.  Round 1, chip-wide
+            // grid: 4.6 -> 2.4 Gpx/s.  Round 2, small grids so that few CUs wait on the link: 3.34 / 2.68 / 2.46 Gpx/s with
+            // 16 / 48 / 128 workgroups per chunk against 5.5 with the staging pass + runtime copy.)
             uint64_t *d = t.dev_rows(c);
-            if (n_rows && mapped) {
-                hipLaunchKernelGGL(k_interleave16, dim3(unsigned(direct_blocks)), dim3(256), 0, t.stream, a, mapped, n_rows);
-                HIP_OK(hipGetLastError());
-            } else if (n_rows) {
+            if (n_rows) {
                 hipLaunchKernelGGL(k_interleave16, dim3((n_rows * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_rows);
                 HIP_OK(hipGetLastError());
+                // (In this pipeline the runtime performs the copy with its blit kernel -- four 32 MB dispatches per 128 MB chunk --
+                // whatever was tried: ring from hipHostMalloc instead of hipHostRegister, 2 / 4 / 8 copy streams, the copy cut
+                // into 8 or 16 MB pieces; the same copy from a bare test program goes through SDMA.  DESIGN.md section 4.)
                 HIP_OK(hipMemcpyAsync(t.rows(c), d, size_t(n_rows) * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
             }
         }
