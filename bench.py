@@ -254,7 +254,7 @@ def main():
     host_buffers = args.host_buffers or (min(B + 16, slots + 16 * coders + 32) + 64 * dev_packs)   # groups in flight + every thread's sixteen + a queue (+ the device coder's packs)
     ctx = pkg.Context(device=gpu, n_slots=slots, n_coders=coders, n_groups=max(1, min(args.groups, slots)),
                       n_host_buffers=host_buffers)
-    ctx.enable_timing(True)
+    ctx.enable_timing(not os.environ.get("NBLIC_BENCH_NO_STAGE_TIMING"))     # (experiment switch: what the per-stage events cost)
     if dev_packs:
         ctx.set_device_coder(dev_packs, args.device_min_outstanding if args.device_min_outstanding >= 0 else int(2.8 * B))
     # streams land in one pinned slab (a slot per frame: worst case seen is 1.0025 B/px) so that the

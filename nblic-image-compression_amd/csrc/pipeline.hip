@@ -417,23 +417,49 @@ static bool launch_front_serial(nblic_amd_ctx *c, Group &g, const uint8_t *const
 }
 
 // ---- bins leave HBM in the layout the host coder wants ---------------------------------------
-// rows[16 * i + lane] = bins 4i .. 4i+3 of lane `lane` as one 64-bit word (zero past the lane's end):
-// a chunk of up to sixteen images becomes ONE contiguous device->host copy (instead of sixteen), and
-// on the host a pack's next four steps are one aligned 64-byte load (instead of an 8-way gather).
+// A chunk of up to sixteen images becomes ONE contiguous device->host copy of 13-bit groups (range_coder.h,
+// layout in range_coder_x8.cpp): rows[(13 * g + j) * 16 + lane] = word j of the thirteen 64-bit words that hold
+// bins 64g .. 64g+63 of lane `lane` (zero past the lane's end).  On the host a pack's word is one aligned
+// 64-byte load, and the link -- which bounds the pipeline -- carries 13 bits per bin instead of 16.
+// One thread produces one WORD: it reads the four records the word's low 52 bits hold (8 bytes) and the record
+// whose probability rides in its top field (2 bytes; word 12 reads the twelve records whose bins it collects) -- all
+// thirteen threads of a group read inside the same 128-byte line, the sixteen lanes of a word sit side by side, and a
+// wave stores four words x sixteen lanes = 512 contiguous bytes.  No LDS and a handful of registers ON PURPOSE: this
+// kernel runs on the coder threads' streams underneath the encoder's own kernels, and what it costs is the time its
+// workgroups wait for a slot, not its memory efficiency.  (Measured in the pipeline, per 4 Mbin chunk: a thread per
+// group fetching its own 128-byte line 3.5 ms; the same with the lines staged through 33 KB of LDS by coalesced
+// loads 5.9 ms -- the big workgroups find a CU late; the 16-bit interleave this replaces 2.8 ms.)
 // (Measured and rejected: letting this kernel store straight into the mapped host ring.  The
 // PCIe-bound waves crowd the encoder's own kernels off the GPU: 4.6 -> 2.4 Gpx/s.)
 struct InterleaveArgs { const uint16_t *src[kMaxTake]; uint32_t len[kMaxTake]; };
-__global__ void __launch_bounds__(256) k_interleave16(InterleaveArgs a, uint64_t *__restrict__ rows, uint32_t n_rows) {
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; (t >> 4) < n_rows; t += gridDim.x * 256u) {
-        const uint32_t lane = t & 15u, pos = 4u * (t >> 4), len = a.len[lane];
-        uint64_t v = 0;
-        if (pos + 4u <= len) {
-            v = *reinterpret_cast<const uint64_t *>(a.src[lane] + pos);  // chunk starts are multiples of 4 bins in 256-byte aligned buffers
+__global__ void __launch_bounds__(256) k_pack_groups(InterleaveArgs a, uint64_t *__restrict__ rows, uint32_t n_words) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = t & 15u, word = t >> 4;               // word = 13 * group + j
+    if (word >= n_words) return;
+    const uint32_t g = word / uint32_t(kGroupWords), j = word - g * uint32_t(kGroupWords);
+    const uint32_t pos = g * uint32_t(kGroupBins), len = a.len[lane];
+    const uint16_t *src = a.src[lane] + pos;                     // chunk starts are multiples of 64 bins in 256-byte aligned buffers
+    auto rec = [&](uint32_t k) { return pos + k < len ? uint64_t(code13(src[k])) : uint64_t(0); };
+    uint64_t v;
+    if (pos + uint32_t(kGroupBins) <= len) {
+        const uint64_t q = *reinterpret_cast<const uint64_t *>(src + 4u * j);
+        v = uint64_t(code13(uint32_t(q) & 0xFFFFu)) | uint64_t(code13(uint32_t(q >> 16) & 0xFFFFu)) << 13 |
+            uint64_t(code13(uint32_t(q >> 32) & 0xFFFFu)) << 26 | uint64_t(code13(uint32_t(q >> 48))) << 39;
+        if (j < 12u) {
+            v |= uint64_t(src[52u + j] & 0xFFFu) << 52;
         } else {
-            for (uint32_t k = 0; k < 4u; k++) if (pos + k < len) v |= uint64_t(a.src[lane][pos + k]) << (16u * k);
+            const uint64_t *tail = reinterpret_cast<const uint64_t *>(src + 52);
+            const uint64_t m = 0x8000800080008000ull;
+            // the four bins of each 8-byte load sit at bits 15, 31, 47, 63: gather them to bits 0..3
+            auto bins4 = [&](uint64_t x) { x &= m; return ((x >> 15) | (x >> 30) | (x >> 45) | (x >> 60)) & 0xFull; };
+            v |= (bins4(tail[0]) | bins4(tail[1]) << 4 | bins4(tail[2]) << 8) << 52;
         }
-        rows[t] = v;
+    } else {                                                     // the lane's last group of the chunk (or nothing at all)
+        v = rec(4u * j) | rec(4u * j + 1u) << 13 | rec(4u * j + 2u) << 26 | rec(4u * j + 3u) << 39;
+        if (j < 12u) v |= (rec(52u + j) & 0xFFFu) << 52;
+        else for (uint32_t e = 0; e < 12u; e++) v |= (rec(52u + e) >> 12) << (52u + e);
     }
+    rows[t] = v;
 }
 
 // What a coder thread owns: a pinned ring of two half-buffers x sixteen lanes x kChunkBins, so chunk
@@ -444,7 +470,7 @@ struct CoderThread {
     hipStream_t stream = nullptr;
     hipEvent_t ev[kRingDepth] = {};
     uint16_t *ring = nullptr;
-    uint64_t *d_rows = nullptr;                          // device: two halves of interleaved rows (k_interleave16's output)
+    uint64_t *d_rows = nullptr;                          // device: two halves of 13-bit groups (k_pack_groups' output)
     uint16_t *whole = nullptr; size_t whole_cap = 0;     // pinned; one whole QNBLIC image (its rANS runs last pixel first)
     RangeX8 x8, x8b;
     RangeScalar x1;
@@ -475,7 +501,7 @@ struct CoderThread {
             if (!ring) { ring_lanes = ring_chunk = 0; fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
             ring_lanes = nl; ring_chunk = nc;
         }
-        const size_t want_rows = need_rows ? kRingDepth * (ring_chunk / 4 * kMaxTake) : 0;
+        const size_t want_rows = need_rows ? kRingDepth * group_words(ring_chunk) : 0;
         if (want_rows > rows_cap) {
             if (d_rows) hipFree(d_rows);
             d_rows = nullptr; rows_cap = 0;
@@ -485,8 +511,8 @@ struct CoderThread {
         return true;
     }
     uint16_t *slot(size_t chunk, int lane) { return ring + (size_t(chunk % kRingDepth) * ring_lanes + size_t(lane)) * ring_chunk; }
-    uint64_t *rows(size_t chunk) { return reinterpret_cast<uint64_t *>(ring) + size_t(chunk % kRingDepth) * (ring_chunk / 4 * kMaxTake); }   // same bytes as the lanes' slots
-    uint64_t *dev_rows(size_t chunk) { return d_rows + size_t(chunk % kRingDepth) * (ring_chunk / 4 * kMaxTake); }
+    uint64_t *rows(size_t chunk) { return reinterpret_cast<uint64_t *>(ring) + size_t(chunk % kRingDepth) * group_words(ring_chunk); }   // inside the bytes of the sixteen lanes' slots (26 of 32 bytes per bin column)
+    uint64_t *dev_rows(size_t chunk) { return d_rows + size_t(chunk % kRingDepth) * group_words(ring_chunk); }
 };
 
 // Streams `take` images' bins from HBM and codes them: one image with the scalar coder, up to
@@ -515,18 +541,18 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
                 a.src[lane_of(k)] = dev[k] + c * chunk_bins; a.len[lane_of(k)] = uint32_t(len);
                 longest = len > longest ? len : longest;
             }
-            const uint32_t n_rows = uint32_t((longest + 3) / 4);
+            const uint32_t n_groups = uint32_t((longest + kGroupBins - 1) / kGroupBins);
             // (Measured and rejected, twice: letting this kernel store straight into the mapped host ring.  Round 1, chip-wide
             // grid: 4.6 -> 2.4 Gpx/s.  Round 2, small grids so that few CUs wait on the link: 3.34 / 2.68 / 2.46 Gpx/s with
             // 16 / 48 / 128 workgroups per chunk against 5.5 with the staging pass + runtime copy.)
             uint64_t *d = t.dev_rows(c);
-            if (n_rows) {
-                hipLaunchKernelGGL(k_interleave16, dim3((n_rows * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_rows);
+            if (n_groups) {
+                hipLaunchKernelGGL(k_pack_groups, dim3((n_groups * uint32_t(kGroupWords) * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_groups * uint32_t(kGroupWords));
                 HIP_OK(hipGetLastError());
                 // (In this pipeline the runtime performs the copy with its blit kernel -- four 32 MB dispatches per 128 MB chunk --
                 // whatever was tried: ring from hipHostMalloc instead of hipHostRegister, 2 / 4 / 8 copy streams, the copy cut
                 // into 8 or 16 MB pieces; the same copy from a bare test program goes through SDMA.  DESIGN.md section 4.)
-                HIP_OK(hipMemcpyAsync(t.rows(c), d, size_t(n_rows) * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
+                HIP_OK(hipMemcpyAsync(t.rows(c), d, group_words(longest) * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
             }
         }
         HIP_OK(hipEventRecord(t.ev[c % kRingDepth], t.stream));
@@ -544,7 +570,7 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
             size_t len[kMaxTake] = {0};
             for (int k = 0; k < take; k++) len[lane_of(k)] = chunk_len(c, k);
             static const bool feed_only = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 128);   // measurement aid: bins reach the host but are not coded
-            if (!feed_only) feed_pair_rows(t.x8, t.x8b, t.rows(c), len);
+            if (!feed_only) feed_pair_groups(t.x8, t.x8b, t.rows(c), len);
         } else {
             t.x1.feed(t.slot(c, 0), chunk_len(c, 0));
         }
@@ -1215,13 +1241,13 @@ int nblic_amd_range_code_chunked(const uint16_t *const *coded, const size_t *n, 
         return 0;
     }
     // as in the coder threads: pack a takes the first half of the streams (lanes 0..), pack b the rest
-    // (lanes 8..), each chunk is laid out in rows of sixteen 64-bit words (here on the host, in the
-    // pipeline by k_interleave16 on the GPU) and fed through feed_pair_rows
+    // (lanes 8..), each chunk is laid out as 13-bit groups (here on the host, in the pipeline by
+    // k_pack_groups on the GPU) and fed through feed_pair_groups
     RangeX8 a, b;
     const int na = (count + 1) / 2;
     a.begin(na, outs, caps);
     b.begin(count - na, outs + na, caps + na);
-    const size_t rows_cap = (chunk + 3) / 4 * 16;
+    const size_t rows_cap = group_words(chunk);
     uint64_t *rows = static_cast<uint64_t *>(aligned_alloc(64, (rows_cap * sizeof(uint64_t) + 63) & ~size_t(63)));
     if (!rows) return -1;
     for (size_t off = 0; off < n_max; off += chunk) {
@@ -1230,9 +1256,9 @@ int nblic_amd_range_code_chunked(const uint16_t *const *coded, const size_t *n, 
         for (int k = 0; k < count; k++) {
             const int lane = k < na ? k : 8 + (k - na);
             len[lane] = off >= n[k] ? 0 : (n[k] - off < chunk ? n[k] - off : chunk);
-            for (size_t i = 0; i < len[lane]; i++) rows[16 * (i >> 2) + size_t(lane)] |= uint64_t(coded[k][off + i]) << (16 * (i & 3));
+            pack_groups_host(rows, lane, coded[k] + off, len[lane]);
         }
-        feed_pair_rows(a, b, rows, len);
+        feed_pair_groups(a, b, rows, len);
     }
     free(rows);
     a.end(lens);
@@ -1288,8 +1314,8 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     // coder threads' short interleave kernels and copies overtake the encoder's long kernels -- the
     // pipeline drops from 4.9 to 3.1 Gpx/s.)
     if (const char *cb = getenv("NBLIC_AMD_CHUNK_BINS")) {
-        const size_t v = size_t(atol(cb)) & ~size_t(3);          // a multiple of four: the rows hold four bins per word
-        if (v >= 4096 && v <= kChunkBins) c->chunk_bins = v;
+        const size_t v = size_t(atol(cb));
+        if (v >= 4096 && v <= kChunkBins) c->chunk_bins = v & ~(kGroupBins - 1);     // chunks start on a group boundary
     }
     int n_copy = n_coders < kCopyStreams ? n_coders : kCopyStreams;
     if (const char *cs = getenv("NBLIC_AMD_COPY_STREAMS")) { const int v = atoi(cs); if (v >= 1 && v <= 32) n_copy = v; }   // experiments with the copy engines

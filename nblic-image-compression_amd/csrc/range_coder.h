@@ -40,6 +40,14 @@ void feed_pair(RangeX8 &a, const uint16_t *const *src_a, const size_t *len_a, Ra
 // (64-byte aligned; lanes 0-7 pack a, 8-15 pack b); len[lane] = the lane's bins in this chunk
 void feed_pair_rows(RangeX8 &a, RangeX8 &b, const uint64_t *rows, const size_t *len);
 
+// the form in which a pack pair's bins cross PCIe: 64 records of a lane as 64 x 13 bits = thirteen 64-bit words,
+// rows[(13 * g + j) * 16 + lane] = word j of the lane's group g (range_coder_x8.cpp, k_pack_groups in pipeline.hip)
+constexpr size_t kGroupBins = 64, kGroupWords = 13;
+constexpr uint32_t code13(uint32_t rec) { return (rec & 0xFFFu) | ((rec >> 3) & 0x1000u); }           // prob | bin << 12
+constexpr size_t group_words(size_t bins) { return (bins + kGroupBins - 1) / kGroupBins * kGroupWords * 16; }   // words of `bins` bins x sixteen lanes
+void feed_pair_groups(RangeX8 &a, RangeX8 &b, const uint64_t *rows, const size_t *len);
+void pack_groups_host(uint64_t *rows, int lane, const uint16_t *coded, size_t len);       // ORs one lane's records into zeroed rows (tests, the chunked self-check)
+
 bool have_avx512();
 size_t range_code(const uint16_t *coded, size_t n, uint8_t *out, size_t cap);
 void range_code_x8(const uint16_t *const *coded, const size_t *n, int count, uint8_t *const *outs, const size_t *caps, size_t *lens);

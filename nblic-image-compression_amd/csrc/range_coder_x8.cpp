@@ -72,11 +72,13 @@ NB_TARGET NB_INLINE __mmask8 renorm_once(Regs &R, Outs &O, __mmask8 k) {
     return k;
 }
 
-// one bin per active lane; ev holds prob | bin << 15 in the low 16 bits of every lane
+// one bin per active lane; ev holds prob in bits 0-11 and the bin at BIN (bit 15 of a raw 16-bit record, bit 12
+// of a 13-bit code); whatever else the lane holds is ignored
+template <long long BIN = 0x8000>
 NB_TARGET NB_INLINE void step(Regs &R, Outs &O, __m512i ev, __mmask8 kact) {
     const __m512i prob = _mm512_and_si512(ev, _mm512_set1_epi64(0xFFF));
     const __m512i t1 = _mm512_add_epi64(_mm512_srli_epi64(_mm512_mul_epu32(R.span, prob), 12), _mm512_set1_epi64(1));
-    const __mmask8 kone = _mm512_test_epi64_mask(ev, _mm512_set1_epi64(0x8000));
+    const __mmask8 kone = _mm512_test_epi64_mask(ev, _mm512_set1_epi64(BIN));
     const __mmask8 k1 = kone & kact, k0 = (__mmask8)(~kone) & kact;
     // bin 1 keeps [lo, cut]: span = t; bin 0 keeps [cut + 1, hi]: lo += t + 1, span -= t + 1
     R.lo = _mm512_mask_add_epi64(R.lo, k0, R.lo, t1);
@@ -97,10 +99,10 @@ NB_TARGET NB_INLINE void step(Regs &R, Outs &O, __m512i ev, __mmask8 kact) {
 // for instruction count: no activity mask, the bin-0 mask straight from a test-not, the interval
 // update as two masked operations, and ONE rarely-taken branch for everything unusual (a full byte
 // accumulator, a second byte in the same step).
-NB_TARGET NB_INLINE void step_all(Regs &R, Outs &O, __m512i ev) {
-    const __m512i tm = _mm512_srli_epi64(_mm512_mul_epu32(R.span, _mm512_and_si512(ev, _mm512_set1_epi64(0xFFF))), 12);
+// (prob: the 12-bit probability alone; k0: the lanes whose bin is 0)
+NB_TARGET NB_INLINE void step_core(Regs &R, Outs &O, __m512i prob, __mmask8 k0) {
+    const __m512i tm = _mm512_srli_epi64(_mm512_mul_epu32(R.span, prob), 12);
     const __m512i t1 = _mm512_add_epi64(tm, _mm512_set1_epi64(1));
-    const __mmask8 k0 = _mm512_testn_epi64_mask(ev, _mm512_set1_epi64(0x8000));           // lanes whose bin is 0
     R.lo = _mm512_mask_add_epi64(R.lo, k0, R.lo, t1);                                        // bin 0: lo += t + 1
     R.span = _mm512_mask_sub_epi64(tm, k0, R.span, t1);                                      // bin 0: span -= t + 1; bin 1: span = t
     const __m512i hi = _mm512_add_epi64(R.lo, R.span);
@@ -120,6 +122,10 @@ NB_TARGET NB_INLINE void step_all(Regs &R, Outs &O, __m512i ev) {
             kk = _mm512_mask_testn_epi64_mask(kk, _mm512_xor_si512(R.lo, _mm512_add_epi64(R.lo, R.span)), _mm512_set1_epi64(0xFF000000ll));
         }
     }
+}
+template <long long BIN = 0x8000>
+NB_TARGET NB_INLINE void step_all(Regs &R, Outs &O, __m512i ev) {
+    step_core(R, O, _mm512_and_si512(ev, _mm512_set1_epi64(0xFFF)), _mm512_testn_epi64_mask(ev, _mm512_set1_epi64(BIN)));
 }
 
 }  // namespace
@@ -279,6 +285,89 @@ NB_TARGET void feed_pair_rows(RangeX8 &A, RangeX8 &B, const uint64_t *rows, cons
         const __mmask8 ka = _mm512_cmplt_epu64_mask(p, la), kb = _mm512_cmplt_epu64_mask(p, lb);
         if (ka) step(RA, OA, _mm512_srlv_epi64(_mm512_load_si512((const void *)row), sh), ka);
         if (kb) step(RB, OB, _mm512_srlv_epi64(_mm512_load_si512((const void *)(row + 8)), sh), kb);
+    }
+    A.st->L.r = RA;
+    B.st->L.r = RB;
+}
+
+// The pair fed from 13-BIT GROUPS -- the form in which bins cross PCIe.  A record is 12 bits of probability and the
+// bin: 13 bits as code13(), and 64 of them are exactly thirteen 64-bit words.  rows[(13 * g + j) * 16 + lane] is word j
+// of lane `lane`'s group g (bins 64g .. 64g+63; zero where the lane has no bin):
+//     bits  0..51 of word j            codes 4j .. 4j+3 of the group, 13 bits each            (52 codes in 13 words)
+//     bits 52..63 of word j, j < 12    the probability of code 52+j
+//     bits 52..63 of word 12           bit e = the bin of code 52+e
+// so that no code straddles two words and the walk is two SHORT loops with constant shifts -- thirteen times four steps
+// per pack exactly as from 16-bit rows, then twelve steps from the top fields.  (First attempt: codes back to back,
+// 13k .. 13k+12 of the 832 bits, the 64 x 2 steps fully unrolled since every one has its own shift -- the compiler kept
+// the coder state on the stack there, and the walk ran 9-15 % slower than from 16-bit rows.)  A pack's word is still ONE
+// aligned 64-byte load, and the link -- which bounds the pipeline -- carries 18.75 % fewer
+// bytes.  k_pack_groups (pipeline.hip) writes the layout; pack_groups_host is the same on the host, for tests.
+void pack_groups_host(uint64_t *rows, int lane, const uint16_t *coded, size_t len) {
+    for (size_t i = 0; i < len; i++) {
+        uint64_t *grp = rows + (i >> 6) * kGroupWords * 16 + size_t(lane);
+        const uint64_t c = code13(coded[i]);
+        const size_t k = i & 63;
+        if (k < 52) grp[16 * (k >> 2)] |= c << (13 * (k & 3));
+        else { grp[16 * (k - 52)] |= (c & 0xFFF) << 52; grp[16 * 12] |= (c >> 12) << (52 + (k - 52)); }
+    }
+}
+
+NB_TARGET void feed_pair_groups(RangeX8 &A, RangeX8 &B, const uint64_t *rows, const size_t *len) {
+    Regs RA = A.st->L.r, RB = B.st->L.r;
+    Outs &OA = A.st->L.o, &OB = B.st->L.o;
+    const int ca = A.st->count, cb = B.st->count;
+    unsigned act_a = 0, act_b = 0;
+    size_t m = SIZE_MAX, longest = 0;
+    alignas(64) uint64_t lv[16];
+    for (int k = 0; k < 16; k++) {
+        const bool on = (k < 8 ? k < ca : k - 8 < cb) && len[k];
+        lv[k] = on ? len[k] : 0;
+        if (on) { (k < 8 ? act_a : act_b) |= 1u << (k & 7); if (len[k] < m) m = len[k]; if (len[k] > longest) longest = len[k]; }
+    }
+    size_t pos = 0;
+    if (act_a == (1u << ca) - 1u && act_b == (1u << cb) - 1u && (act_a | act_b)) {
+        for (; pos + kGroupBins <= m; pos += kGroupBins) {
+            const uint64_t *grp = rows + (pos >> 6) * (kGroupWords * 16);
+            for (int j = 0; j < int(kGroupWords); j++) {
+                const uint64_t *row = grp + 16 * j;
+                _mm_prefetch((const char *)(row + 2 * kGroupWords * 16), _MM_HINT_T0);
+                _mm_prefetch((const char *)(row + 2 * kGroupWords * 16 + 8), _MM_HINT_T0);
+                const __m512i ga = _mm512_load_si512((const void *)row), gb = _mm512_load_si512((const void *)(row + 8));
+                step_all<0x1000>(RA, OA, ga);                         step_all<0x1000>(RB, OB, gb);
+                step_all<0x1000>(RA, OA, _mm512_srli_epi64(ga, 13));  step_all<0x1000>(RB, OB, _mm512_srli_epi64(gb, 13));
+                step_all<0x1000>(RA, OA, _mm512_srli_epi64(ga, 26));  step_all<0x1000>(RB, OB, _mm512_srli_epi64(gb, 26));
+                step_all<0x1000>(RA, OA, _mm512_srli_epi64(ga, 39));  step_all<0x1000>(RB, OB, _mm512_srli_epi64(gb, 39));
+            }
+            const __m512i ba = _mm512_load_si512((const void *)(grp + 16 * 12)), bb = _mm512_load_si512((const void *)(grp + 16 * 12 + 8));
+            __m512i bit = _mm512_set1_epi64(1ll << 52);
+            for (int e = 0; e < 12; e++) {
+                const uint64_t *row = grp + 16 * e;
+                step_core(RA, OA, _mm512_srli_epi64(_mm512_load_si512((const void *)row), 52), _mm512_testn_epi64_mask(ba, bit));
+                step_core(RB, OB, _mm512_srli_epi64(_mm512_load_si512((const void *)(row + 8)), 52), _mm512_testn_epi64_mask(bb, bit));
+                bit = _mm512_slli_epi64(bit, 1);
+            }
+        }
+    }
+    // whatever is left (lanes of different length, a pack with idle lanes): one bin at a time, lanes masked by their length
+    const __m512i la = _mm512_load_si512((const void *)lv), lb = _mm512_load_si512((const void *)(lv + 8));
+    for (; pos < longest; pos++) {
+        const uint64_t *grp = rows + (pos >> 6) * (kGroupWords * 16);
+        const size_t k = pos & 63;
+        const __m512i p = _mm512_set1_epi64((long long)pos);
+        const __mmask8 ka = _mm512_cmplt_epu64_mask(p, la), kb = _mm512_cmplt_epu64_mask(p, lb);
+        for (int half = 0; half < 2; half++) {
+            const __mmask8 kk = half ? kb : ka;
+            if (!kk) continue;
+            __m512i ev;
+            if (k < 52) {
+                ev = _mm512_srl_epi64(_mm512_load_si512((const void *)(grp + 16 * (k >> 2) + 8 * half)), _mm_cvtsi64_si128((long long)(13 * (k & 3))));
+            } else {
+                const __m512i bin = _mm512_srl_epi64(_mm512_load_si512((const void *)(grp + 16 * 12 + 8 * half)), _mm_cvtsi64_si128((long long)(52 + (k - 52))));
+                ev = _mm512_or_si512(_mm512_srli_epi64(_mm512_load_si512((const void *)(grp + 16 * (k - 52) + 8 * half)), 52),
+                                     _mm512_and_si512(_mm512_slli_epi64(bin, 12), _mm512_set1_epi64(0x1000)));
+            }
+            if (half) step<0x1000>(RB, OB, ev, kk); else step<0x1000>(RA, OA, ev, kk);
+        }
     }
     A.st->L.r = RA;
     B.st->L.r = RB;
