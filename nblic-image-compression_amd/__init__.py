@@ -496,7 +496,7 @@ class Context:
         return b.value, s.value
 
     _STAGE = {"rec1": (0, np.uint32), "pxs": (1, np.uint16), "z": (2, np.uint8), "cnt": (3, np.uint8),
-              "events": (4, np.uint32), "coded": (5, np.uint16), "dbg": (6, np.uint64)}
+              "events": (4, np.uint32), "coded": (5, np.uint16), "dbg": (6, np.uint64), "totals": (7, np.uint32)}
 
     def debug_stage(self, img: np.ndarray, name: str) -> np.ndarray:
         """Intermediate array of the staged -e1 pipeline for one image (kernel parity tests)."""

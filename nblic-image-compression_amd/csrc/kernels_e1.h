@@ -10,6 +10,7 @@ constexpr uint32_t kMaxSegments = 1024;   // waves per partition pass (pixel par
 // 4 M partially written lines (512 MB) -- more than the 256 MB Infinity Cache, and rocprof showed
 // 9x write amplification.  256 waves per image keep the open lines of a launch resident.
 constexpr uint32_t kTouchSegments = 256;
+constexpr int kTotalsStride = 8, kWideTouchFlag = 4;      // words per image in the totals array; index of the wide-position flag
 
 struct SegPlan { int nseg; uint32_t seg_len; };
 SegPlan make_plan(uint32_t n_items, uint32_t max_segments = kMaxSegments);
@@ -33,13 +34,13 @@ struct E1Buffers {
     uint32_t *ev_off;        // n      exclusive scan of cnt
     uint32_t *table;         // 4096 * kMaxSegments   partition histogram / offsets
     uint32_t *scan_sums;     // scan scratch
-    uint32_t *totals;        // [4] item totals: adr, mapper, events, touches
+    uint32_t *totals;        // [kTotalsStride] item totals: adr, mapper, events, touches; [kWideTouchFlag] 1 = this image needs 32-bit touch positions
     int      *ctx_state;     // 2048
     int      *map_state;     // 512 * 60
     int      *cnt_state;     // 4096 * 2
     uint32_t *events;        // ev_cap        model.h pack_event
     uint16_t *tin;           // 2*ev_cap+pad  touch payloads grouped by counter
-    uint64_t *tpos;          // ev_cap + 64   two u32 arrays (even trees, odd trees): position of the event's touch in tin/tout, or ~0
+    uint64_t *tpos;          // ev_cap + 64   two u32 arrays (even trees, odd trees): position of the event's touch in tin/tout (28 bits, all ones = none) with qw / bin / parity in the top four bits (kernels_e1.hip pack_pos); plain 32-bit positions, ~0 = none, for an image with >= 2^28 - 1 touches
     uint16_t *tout;          // 2*ev_cap+pad  P(bin==1) before each touch, same order as tin
     uint32_t *blk_base;      // 2049          first block of every context chain (+ total)
     int      *blk_end;       // n/4096+2048   context state at the end of each block

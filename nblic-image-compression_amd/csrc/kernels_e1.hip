@@ -335,6 +335,8 @@ __global__ void __launch_bounds__(256) k_adr_count(const E1Job *__restrict__ job
     const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
+    // the scan that follows raises this flag for an image with too many touches for 28-bit positions (k_touch_scatter)
+    if (seg == 0 && lane_id() == 0) gptr(J.b.totals)[kWideTouchFlag] = (J.dbg & 256) ? 1u : 0u;   // (NBLIC_AMD_DBG & 256: plain 32-bit positions for every image -- tests, A/B runs)
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<M::kKeys>(hist, 0);
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
@@ -521,6 +523,8 @@ __global__ void __launch_bounds__(256) k_map_count(const E1Job *__restrict__ job
     const uint32_t n = J.n; const SegPlan plan = J.pp;
     int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
+    // the scan that follows raises this flag for an image with too many touches for 28-bit positions (k_touch_scatter)
+    if (seg == 0 && lane_id() == 0) gptr(J.b.totals)[kWideTouchFlag] = (J.dbg & 256) ? 1u : 0u;   // (NBLIC_AMD_DBG & 256: plain 32-bit positions for every image -- tests, A/B runs)
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<512>(hist, 0);
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
@@ -572,6 +576,8 @@ __global__ void __launch_bounds__(256) k_map_count_pre(const E1Job *__restrict__
     const NearParams np = near_params(J.near);
     int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
+    // the scan that follows raises this flag for an image with too many touches for 28-bit positions (k_touch_scatter)
+    if (seg == 0 && lane_id() == 0) gptr(J.b.totals)[kWideTouchFlag] = (J.dbg & 256) ? 1u : 0u;   // (NBLIC_AMD_DBG & 256: plain 32-bit positions for every image -- tests, A/B runs)
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<512>(hist, 0);
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n, lo + plan.seg_len);
@@ -758,6 +764,11 @@ __device__ __forceinline__ Touch touch_of(uint32_t e, int parity) {
     return t;
 }
 
+// (Measured and rejected in round 2: counting inside k_emit_bins while the event is in a register -- a workgroup-wide
+// LDS histogram handed to the table with one global atomic per non-empty key after sixteen 256-pixel tiles.  It saves
+// this kernel's read of all events (17.8 B/px) and a launch, the two kernels' time under load drops from 13.8 to
+// 8.7 ms per launch -- and the pipeline runs 2.5 % SLOWER (5.42 against 5.56 Gpx/s, alternating runs on one box):
+// the device-scope atomics land in everybody else's way.  Flushing per tile was worse still: 19.6 ms.)
 __global__ void __launch_bounds__(256) k_touch_count(const E1Job *__restrict__ jobs) {
     __shared__ uint32_t lds[4][4096];
     const E1Job &J = jobs[blockIdx.y];
@@ -765,6 +776,8 @@ __global__ void __launch_bounds__(256) k_touch_count(const E1Job *__restrict__ j
     const uint32_t n_ev = J.n_ev; const SegPlan plan = J.pe;
     int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
+    // the scan that follows raises this flag for an image with too many touches for 28-bit positions (k_touch_scatter)
+    if (seg == 0 && lane_id() == 0) gptr(J.b.totals)[kWideTouchFlag] = (J.dbg & 256) ? 1u : 0u;   // (NBLIC_AMD_DBG & 256: plain 32-bit positions for every image -- tests, A/B runs)
     uint32_t *hist = lds[threadIdx.x >> 6];
     lds_fill<4096>(hist, 0);
     uint32_t lo = uint32_t(seg) * plan.seg_len, hi = min(n_ev, lo + plan.seg_len);
@@ -801,6 +814,15 @@ __global__ void __launch_bounds__(256) k_touch_count(const E1Job *__restrict__ j
 //   a group of more than 32 (flat images) goes straight to HBM after the ring has been drained.
 constexpr int kStageSlots = 64, kStageRing = 64;
 constexpr uint32_t kNoTouch = 0xFFFFFFFFu;
+// narrow position words: pos (28 bits, all ones = no touch) | extra << 28, extra = qw[0:4) in the even-tree word and
+// qw[4:6) | bin << 2 | (qu odd) << 3 in the odd-tree word
+constexpr int kPosBits = 28;
+constexpr uint32_t kPosMask = (1u << kPosBits) - 1u;
+__device__ __forceinline__ uint32_t pack_pos(uint32_t pos, uint32_t e, int parity) {
+    const uint32_t qw = uint32_t(ev_qw(e));
+    const uint32_t extra = parity == 0 ? (qw & 15u) : ((qw >> 4) | (uint32_t(ev_bin(e)) << 2) | (uint32_t(ev_qu(e) & 1) << 3));
+    return (pos & kPosMask) | (extra << kPosBits);
+}
 struct alignas(16) TouchLds {
     uint32_t off[2048];                      // next position of every chain of this parity
     uint16_t ring[kStageSlots][kStageRing];
@@ -822,6 +844,10 @@ __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__
     const auto tin = gptr(J.b.tin);
     const uint32_t n_ev = J.n_ev; const SegPlan plan = J.pe;
     const int parity = int(blockIdx.z);
+    // a position needs 28 bits (kPosBits) for every frame the reference accepts at ordinary bin counts; the four
+    // spare bits of the two words carry what k_mix would otherwise re-read the event for (see there).  An image
+    // with 2^28 - 1 touches or more sets the flag in the scan and keeps plain 32-bit positions.
+    const bool wide = gptr(J.b.totals)[kWideTouchFlag] != 0u;
     const auto posP = (NB_GLOBAL uint32_t *)gptr(J.b.tpos) + size_t(parity) * ((size_t(n_ev) + 63) & ~size_t(63));
     const int seg = int(xcd_block()) * 4 + int(threadIdx.x >> 6);
     if (seg >= plan.nseg) return;
@@ -908,7 +934,7 @@ __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__
             if (lane == s_sl) my_flushed = big ? s_now : upto;
         }
         if (stamp) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_close += t1 - t0; }
-        if (r < hi) posP[r] = pos;
+        if (r < hi) posP[r] = wide ? pos : pack_pos(pos, e, parity);
     };
     const unsigned long long t_setup = __builtin_amdgcn_s_memtime() - t_begin;
     // The walk is serial in the chain offsets, so the event loads must not be.  On this ISA loads
@@ -1191,22 +1217,31 @@ __global__ void __launch_bounds__(256) k_counter_probs(const E1Job *__restrict__
 }
 
 // ---- mix the two trees' probabilities and pack for the host coder (NBLIC.c:629-633) -------
+// k_touch_scatter files an event's touch positions by tree PARITY; tree u is the one with qu's parity, and an event
+// without a second touch (both trees equal, or weight 0) mixes its one P with itself.  The two position words also
+// carry qw, the bin and qu's parity in their top four bits (pack_pos), so the event itself is not read again
+// (4 of 12 bytes per event) -- unless the image has too many touches for 28-bit positions (flag set by the scan).
 __global__ void __launch_bounds__(256) k_mix(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
-    const auto events = gptr(J.b.events); const auto tout = gptr(J.b.tout);
-    const auto pos0 = (NB_GLOBAL const uint32_t *)gptr(J.b.tpos); const auto coded = gptr(J.b.coded);
+    const auto tout = gptr(J.b.tout); const auto coded = gptr(J.b.coded);
+    const auto pos0 = (NB_GLOBAL const uint32_t *)gptr(J.b.tpos);
     const auto pos1 = pos0 + ((size_t(J.n_ev) + 63) & ~size_t(63));
-    uint32_t r = xcd_block() * 256u + threadIdx.x;
+    const uint32_t r = xcd_block() * 256u + threadIdx.x;
     if (r >= J.n_ev) return;
-    uint32_t e = events[r];
-    // k_touch_scatter files positions by tree PARITY; tree u is the one with qu's parity, and an
-    // event without a second touch (both trees equal, or weight 0) mixes its one P with itself
-    const uint32_t p0 = pos0[r], p1 = pos1[r];
-    const bool odd = (ev_qu(e) & 1) != 0;
+    uint32_t p0 = pos0[r], p1 = pos1[r];
+    int qw, bin; bool odd;
+    if (gptr(J.b.totals)[kWideTouchFlag] != 0u) {
+        const uint32_t e = gptr(J.b.events)[r];
+        qw = ev_qw(e); bin = ev_bin(e); odd = (ev_qu(e) & 1) != 0;
+    } else {
+        qw = int((p0 >> kPosBits) | (((p1 >> kPosBits) & 3u) << 4)); bin = int((p1 >> (kPosBits + 2)) & 1u); odd = (p1 >> 31) != 0u;
+        p0 &= kPosMask; p1 &= kPosMask;
+        if (p0 == kPosMask) p0 = kNoTouch;
+        if (p1 == kPosMask) p1 = kNoTouch;
+    }
     const uint32_t at_u = odd ? p1 : p0, other = odd ? p0 : p1, at_v = other == kNoTouch ? at_u : other;
-    int qw = ev_qw(e);
-    int pu = tout[at_u], pv = tout[at_v];
-    coded[r] = pack_coded(mix_prob(pu, pv, qw), ev_bin(e));
+    const int pu = tout[at_u], pv = tout[at_v];
+    coded[r] = pack_coded(mix_prob(pu, pv, qw), bin);
 }
 
 // ---- model state init (NBLIC.c:797-804) ---------------------------------------------------
@@ -1272,7 +1307,10 @@ __global__ void __launch_bounds__(1024) k_scan_sums(const E1Job *__restrict__ jo
         if (threadIdx.x == 1023) carry = pre + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) gptr(J.b.totals)[WHICH & 3] = carry;
+    if (threadIdx.x == 0) {
+        gptr(J.b.totals)[WHICH & 3] = carry;
+        if (WHICH == 3 && carry >= kPosMask) gptr(J.b.totals)[kWideTouchFlag] = 1u;          // touches: too many for 28-bit positions
+    }
 }
 
 template <int WHICH>

@@ -182,7 +182,7 @@ struct Group {
     E1Job *h_jobs = nullptr, *d_jobs = nullptr;        // pinned host / device job records
     SerialJob *h_sjobs = nullptr, *d_sjobs = nullptr;  // the same images for the serial model stage (kind 2)
     unsigned char *const *recons = nullptr;            // kind 2: where each image's reconstruction goes (host; entries may be null)
-    uint32_t *h_totals = nullptr, *d_totals = nullptr; // 4 words per slot
+    uint32_t *h_totals = nullptr, *d_totals = nullptr; // kTotalsStride words per slot
     int n_jobs = 0;
     bool tm_pending = false;                           // timer events recorded, not yet read
     ::nblic_amd_ctx *ctx = nullptr;
@@ -281,13 +281,13 @@ static bool group_init(Group &g, int id, int n_slots, nblic_amd_ctx *c) {
     HIP_OK(hipMalloc((void **)&g.d_jobs, size_t(n_slots) * sizeof(E1Job)));
     HIP_OK(hipHostMalloc((void **)&g.h_sjobs, size_t(n_slots) * sizeof(SerialJob), hipHostMallocDefault));
     HIP_OK(hipMalloc((void **)&g.d_sjobs, size_t(n_slots) * sizeof(SerialJob)));
-    HIP_OK(hipHostMalloc((void **)&g.h_totals, size_t(n_slots) * 4 * sizeof(uint32_t), hipHostMallocDefault));
-    HIP_OK(hipMalloc((void **)&g.d_totals, size_t(n_slots) * 4 * sizeof(uint32_t)));
+    HIP_OK(hipHostMalloc((void **)&g.h_totals, size_t(n_slots) * kTotalsStride * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_OK(hipMalloc((void **)&g.d_totals, size_t(n_slots) * kTotalsStride * sizeof(uint32_t)));
     for (int k = 0; k < n_slots; k++) {
         Slot &s = g.slots[size_t(k)];
         HIP_OK(hipMalloc((void **)&s.b.table, size_t(4096) * kMaxSegments * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.scan_sums, size_t(1) << 20));
-        s.b.totals = g.d_totals + size_t(k) * 4;
+        s.b.totals = g.d_totals + size_t(k) * kTotalsStride;
         HIP_OK(hipMalloc((void **)&s.b.ctx_state, 4096 * sizeof(int)));           // 2048 (NBLIC) or 3072 (QNBLIC) contexts
         HIP_OK(hipMalloc((void **)&s.b.qhist, 12 * 256 * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.map_state, 512 * 60 * sizeof(int)));
@@ -359,7 +359,7 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
     e1_launch_front(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);
-    HIP_OK(hipMemcpyAsync(g.h_totals, g.d_totals, size_t(g.n_jobs) * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    HIP_OK(hipMemcpyAsync(g.h_totals, g.d_totals, size_t(g.n_jobs) * kTotalsStride * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
     return true;
 }
 
@@ -412,7 +412,7 @@ static bool launch_front_serial(nblic_amd_ctx *c, Group &g, const uint8_t *const
         else if (on_device) HIP_OK(hipMemcpyAsync(dst, imgs[s.job], n, hipMemcpyDeviceToHost, g.stream));
     }
     e1_launch_front_pre(g.d_jobs, g.h_jobs, g.n_jobs, g.stream);
-    HIP_OK(hipMemcpyAsync(g.h_totals, g.d_totals, size_t(g.n_jobs) * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    HIP_OK(hipMemcpyAsync(g.h_totals, g.d_totals, size_t(g.n_jobs) * kTotalsStride * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
     return true;
 }
 
@@ -546,13 +546,14 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
             // grid: 4.6 -> 2.4 Gpx/s.  Round 2, small grids so that few CUs wait on the link: 3.34 / 2.68 / 2.46 Gpx/s with
             // 16 / 48 / 128 workgroups per chunk against 5.5 with the staging pass + runtime copy.)
             uint64_t *d = t.dev_rows(c);
+            static const int feed_dbg = getenv("NBLIC_AMD_DBG") ? atoi(getenv("NBLIC_AMD_DBG")) : 0;      // measurement aids (with & 128): & 512 no pack kernel, & 1024 no copy
             if (n_groups) {
-                hipLaunchKernelGGL(k_pack_groups, dim3((n_groups * uint32_t(kGroupWords) * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_groups * uint32_t(kGroupWords));
+                if (!(feed_dbg & 512)) hipLaunchKernelGGL(k_pack_groups, dim3((n_groups * uint32_t(kGroupWords) * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_groups * uint32_t(kGroupWords));
                 HIP_OK(hipGetLastError());
                 // (In this pipeline the runtime performs the copy with its blit kernel -- four 32 MB dispatches per 128 MB chunk --
                 // whatever was tried: ring from hipHostMalloc instead of hipHostRegister, 2 / 4 / 8 copy streams, the copy cut
                 // into 8 or 16 MB pieces; the same copy from a bare test program goes through SDMA.  DESIGN.md section 4.)
-                HIP_OK(hipMemcpyAsync(t.rows(c), d, group_words(longest) * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
+                if (!(feed_dbg & 1024)) HIP_OK(hipMemcpyAsync(t.rows(c), d, group_words(longest) * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
             }
         }
         HIP_OK(hipEventRecord(t.ev[c % kRingDepth], t.stream));
@@ -811,7 +812,7 @@ static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders, bool gener
     HIP_OK(hipEventSynchronize(g.done));
     for (int k = 0; k < g.n_jobs; k++) {
         Slot &s = g.slots[size_t(k)];
-        s.n_ev = g.h_totals[size_t(k) * 4 + 2];
+        s.n_ev = g.h_totals[size_t(k) * kTotalsStride + 2];
         if (s.n_ev >= 0x7FFFFFFFu) { fprintf(stderr, "[nblic_amd] event count overflow\n"); return false; }
         if (!ensure_events(s, s.n_ev)) return false;
         // the coded bins go straight into a pool buffer that outlives this group's turn on the slot
@@ -1423,6 +1424,7 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
             case 4: src = s.b.events; esz = 4; cnt = s.n_ev; break;
             case 5: src = s.b.coded; esz = 2; cnt = s.n_ev; break;
             case 6: src = s.b.dbg_out; esz = 8; cnt = 4096; break;
+            case 7: src = s.b.totals; esz = 4; cnt = size_t(kTotalsStride); break;       // [kWideTouchFlag]: 32-bit touch positions were needed
             default: break;
         }
         if (src && cnt * esz <= out_bytes && hipMemcpy(out, src, cnt * esz, hipMemcpyDeviceToHost) == hipSuccess) count = long(cnt);

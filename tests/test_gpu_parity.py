@@ -1,11 +1,16 @@
 """GPU suite (-m gpu): the HIP path, called through the C ABI, against the oracle and the
 committed golden fixtures.  Bit-exact is the bar for every stage and every stream."""
 import hashlib
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 import inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -89,6 +94,33 @@ def test_flat_and_structured_images_multi_block(gpu_ctx, oracle):
     got = gpu_ctx.encode_batch(imgs)
     for k, (img, g) in enumerate(zip(imgs, got)):
         assert g == oracle.encode(img, 0, 1)[0], k
+
+
+def test_touch_positions_packed_and_the_plain_32_bit_fallback(gpu_ctx, pkg, oracle):
+    """k_touch_scatter hands k_mix 28-bit positions with qw / bin / parity in the spare bits; an image with 2^28 - 1
+    touches or more (hundreds of megabins) keeps plain 32-bit positions and k_mix re-reads the events.  The fallback
+    is forced here through the library's debug switch, in a process of its own (the switch is read once)."""
+    WIDE_FLAG = 4                                             # kernels_e1.h kWideTouchFlag
+    busy = pkg.syn1(1024, 1024, 3)
+    assert gpu_ctx.debug_stage(busy, "totals")[WIDE_FLAG] == 0
+    code = (
+        "import importlib, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch; torch.cuda.init()\n"
+        "import inputs\n"
+        "from oracle.oracle import Oracle\n"
+        "pkg = importlib.import_module('nblic-image-compression_amd')\n"
+        "ctx = pkg.Context(0, n_slots=4, n_coders=2)\n"
+        "imgs = [pkg.syn1(700, 900, 5), inputs.make('noise', 300, 400), inputs.make('const', 200, 300), inputs.make('ramp', 256, 256)]\n"
+        "assert ctx.debug_stage(imgs[0], 'totals')[4] == 1\n"
+        "o = Oracle()\n"
+        "for img, got in zip(imgs, ctx.encode_batch(imgs)):\n"
+        "    assert got == o.encode(img, 0, 1)[0], img.shape\n"
+        "print('wide ok')\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, NBLIC_AMD_DBG="256")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "wide ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_output_capacity_is_enforced(gpu_ctx):
