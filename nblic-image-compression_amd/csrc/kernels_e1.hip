@@ -62,16 +62,29 @@ __device__ __forceinline__ uint32_t xcd_block() {
     return (b & 7u) * per + (b >> 3);
 }
 
-// Mask of the valid lanes holding the same BITS-bit key as this lane.
+// the 32-bit LDS address of an object in __shared__ memory (for hand-issued ds_ instructions)
+template <class T>
+__device__ __forceinline__ uint32_t lds_address(const T *p) {
+    return uint32_t(uintptr_t((const __attribute__((address_space(3))) T *)p));
+}
+
+// Mask of the valid lanes holding the same BITS-bit key as this lane.  Per key bit: the bit spread over the lane's
+// word (v_bfe_i32: 0 or ~0), one compare for the ballot of the lanes that have it set, and the lanes that DIFFER from
+// this one in that bit are ballot ^ spread -- accumulated with ORs, inverted once at the end.  Six VALU operations per
+// bit; the scatter kernels' walks are bound by VALU issue (a wave64 operation occupies its SIMD for four cycles, and
+// k_touch_scatter holds two waves per SIMD), and the first formulation -- a select between the ballot and its
+// complement per bit, with the validity folded into every ballot -- compiled to twelve.
 template <int BITS>
 __device__ __forceinline__ uint64_t match_lanes(uint32_t key, bool valid) {
-    uint64_t m = __ballot(valid);
+    uint32_t dlo = 0u, dhi = 0u;
 #pragma unroll
     for (int b = 0; b < BITS; b++) {
-        bool bit = (key >> b) & 1u;
-        uint64_t set = __ballot(valid && bit);
-        m &= bit ? set : ~set;
+        const int spread = __builtin_amdgcn_sbfe(int(key), uint32_t(b), 1u);
+        const uint64_t set = __builtin_amdgcn_ballot_w64(spread != 0);          // invalid lanes vote too; they are masked out below
+        dlo |= uint32_t(set) ^ uint32_t(spread);
+        dhi |= uint32_t(set >> 32) ^ uint32_t(spread);
     }
+    const uint64_t m = ~((uint64_t(dhi) << 32) | dlo) & __builtin_amdgcn_ballot_w64(valid);
     return valid ? m : 0ull;
 }
 
@@ -746,21 +759,17 @@ __global__ void __launch_bounds__(256) k_emit_bins(const E1Job *__restrict__ job
 struct Touch { bool valid; uint32_t key; uint32_t payload; int slot; };
 
 __device__ __forceinline__ Touch touch_of(uint32_t e, int parity) {
-    int qu = ev_qu(e), qv = ev_qv(e), node = ev_node(e), qw = ev_qw(e), bin = ev_bin(e);
-    Touch t{false, 0u, 0u, 0};
-    int tree, w1, w2 = 0, dbl = 0;
-    if (qu == qv) {
-        if ((qu & 1) != parity) return t;
-        tree = qu; w1 = kWeightOne - qw; w2 = qw; dbl = 1;
-    } else if ((qu & 1) == parity) {
-        tree = qu; w1 = kWeightOne - qw;
-    } else {
-        if (qw == 0) return t;                   // weight-0 touch: no state change, its P is multiplied by 0
-        tree = qv; w1 = qw; t.slot = 1;
-    }
-    t.valid = true;
+    // branch-free (selects): the scatter walk is bound by instruction issue, and as nested ifs this compiled to ten branches
+    const int qu = ev_qu(e), qv = ev_qv(e), node = ev_node(e), qw = ev_qw(e), bin = ev_bin(e);
+    const bool same = qu == qv;                  // one counter touched twice: weights 32-qw then qw, a "double" item
+    const bool mine = (qu & 1) == parity;        // tree u is the one of this parity (else tree v, unless the trees coincide)
+    Touch t;
+    t.valid = mine || (!same && qw != 0);        // a weight-0 touch changes no state and its P is multiplied by 0
+    const int tree = mine ? qu : qv;
+    const int w1 = mine ? kWeightOne - qw : qw;
+    t.slot = mine ? 0 : 1;
     t.key = uint32_t(parity) * 2048u + uint32_t(tree >> 1) * 256u + uint32_t(node);
-    t.payload = uint32_t(w1) | (uint32_t(w2) << 6) | (uint32_t(bin) << 12) | (uint32_t(dbl) << 13);
+    t.payload = uint32_t(w1) | (same ? uint32_t(qw) << 6 | 1u << 13 : 0u) | (uint32_t(bin) << 12);
     return t;
 }
 
@@ -837,6 +846,7 @@ __device__ __forceinline__ void flush_range(TouchLds &L, NB_GLOBAL uint16_t *tin
     if (e < b) tin[e] = L.ring[sl][e & (kStageRing - 1)];
 }
 
+template <bool STAMP>      // cycle stamps per phase of the walk (E1Job::dbg & 8): compiled out of the production kernel
 __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__ jobs) {
     __shared__ TouchLds lds[4];
     const E1Job &J = jobs[blockIdx.y];
@@ -853,7 +863,7 @@ __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__
     if (seg >= plan.nseg) return;
     TouchLds &L = lds[threadIdx.x >> 6];
     const int lane = lane_id();
-    const bool stamp = (J.dbg & 8) != 0;
+    constexpr bool stamp = STAMP;
     unsigned long long t_begin = __builtin_amdgcn_s_memtime(), t_match = 0, t_place = 0, t_close = 0, t0 = 0;
     // chain starts and this segment's touch count per chain (32 chains per lane)
     uint32_t cnt[32], most = 0;
@@ -900,9 +910,17 @@ __global__ void __launch_bounds__(256) k_touch_scatter(const E1Job *__restrict__
         const bool valid = r < hi && t.valid;
         const uint32_t key = t.key & 2047u;
         if (stamp) t0 = __builtin_amdgcn_s_memtime();
-        const uint32_t chain_off = L.off[key];                  // asked for before the ballots, consumed after them
-        const int chain_slot = int(L.slot[key]) - 1;
+        // asked for before the ballots, consumed after them.  Issued by hand: left to the compiler the two reads are
+        // sunk into the `valid` branch behind the match, and their latency is paid instead of hidden.  (LDS operations
+        // return in order, so the compiler's own lgkmcnt waits only become more conservative with these in flight.)
+        uint32_t chain_off, slot_raw;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_u8 %1, %3"
+                     : "=&v"(chain_off), "=&v"(slot_raw) : "v"(lds_address(&L.off[key])), "v"(lds_address(&L.slot[key])) : "memory");
+        __builtin_amdgcn_sched_barrier(0);                      // the match stays between the reads and the wait
         const uint64_t same = match_lanes<11>(key, valid);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(chain_off), "+v"(slot_raw) : : "memory");
+        const int chain_slot = int(slot_raw) - 1;
         if (stamp) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_match += t1 - t0; t0 = t1; }
         uint32_t pos = kNoTouch;
         int slv = -1;
@@ -1492,7 +1510,9 @@ void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
     else hipLaunchKernelGGL(k_emit_bins<false>, dim3(pad8(cdiv(max_n, 256)), n_jobs), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_touch_count, seg_grid, dim3(256), 0, s, d_jobs);
     scan_exclusive<3>(d_jobs, n_jobs, 4096u * max_nseg, s, mark);
-    mark(); hipLaunchKernelGGL(k_touch_scatter, dim3(seg_grid.x, seg_grid.y, 2), dim3(256), 0, s, d_jobs);
+    mark();
+    if (h_jobs[0].dbg & 8) hipLaunchKernelGGL(k_touch_scatter<true>, dim3(seg_grid.x, seg_grid.y, 2), dim3(256), 0, s, d_jobs);
+    else hipLaunchKernelGGL(k_touch_scatter<false>, dim3(seg_grid.x, seg_grid.y, 2), dim3(256), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_plan_windows, dim3(1, n_jobs), dim3(1024), 0, s, d_jobs);
     mark(); hipLaunchKernelGGL(k_counter_epochs, dim3(4096, n_jobs), dim3(64), 0, s, d_jobs);
     const unsigned max_windows = unsigned(2ull * max_ev / kWin) + 4096u;          // every touch list has <= 2 touches per bin
