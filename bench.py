@@ -148,7 +148,8 @@ def host_description():
     except AttributeError:
         cpus = os.cpu_count() or 1
     toggles = {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "NBLIC_AMD_HOSTMALLOC", "NBLIC_AMD_CHUNK_BINS", "NBLIC_AMD_DBG",
-                                          "NBLIC_AMD_NO_SIMD", "NBLIC_AMD_DEVICE", "NBLIC_BENCH_DEVICE") if k in os.environ}
+                                          "NBLIC_AMD_NO_SIMD", "NBLIC_AMD_DEVICE", "NBLIC_BENCH_DEVICE", "NBLIC_AMD_COPY_STREAMS",
+                                          "NBLIC_BENCH_NO_STAGE_TIMING", "NBLIC_BENCH_SYSTEM_HIP", "DEBUG_CLR_LIMIT_BLIT_WG", "HSA_CU_MASK") if k in os.environ}
     return {"cpu_model": model, "cpus_used_by_this_rank": cpus, "cpus_total": os.cpu_count(), "env": toggles}
 
 
@@ -194,6 +195,10 @@ def main():
         if share:
             os.sched_setaffinity(0, share)              # before torch / HIP start their threads: they inherit it
 
+    if os.environ.get("NBLIC_BENCH_SYSTEM_HIP"):            # experiment: /opt/rocm's HIP + HSA runtimes instead of the ones bundled in the torch wheel
+        import ctypes
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
     import numpy as np
     import torch
     import torch.distributed as dist
