@@ -447,7 +447,8 @@ def main():
             "host_coder_Mbins_per_s_per_thread": round(bins / coder_s / 1e6, 1) if coder_s > 0 else None,
             "device_coder": dev_stats,
             # the device -> host feed of the host coder stage: 2 bytes per coded bin over PCIe (spec 63 GB/s)
-            "d2h_bytes_per_bin": 2, "d2h_GB_per_s": round(bins / steps_counted * args.steps * 2 / dt / 1e9, 2),
+            # coded bins cross PCIe as 13-bit groups: 64 bins in thirteen 64-bit words (range_coder.h kGroupWords)
+            "d2h_bytes_per_bin": 13.0 / 8.0, "d2h_GB_per_s": round(bins / steps_counted * args.steps * (13.0 / 8.0) / dt / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": profiled_traffic(dom, imgs_per_launch),
                          "launch_ms": round(per_launch[dom], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
