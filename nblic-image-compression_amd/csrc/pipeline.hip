@@ -23,6 +23,8 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
 #include <sys/mman.h>
 
 #include "../../include/nblic_amd.h"
@@ -218,6 +220,7 @@ struct nblic_amd_ctx {
     bool trace = false;                      // NBLIC_AMD_DBG & 64: timeline of groups and coder takes on stderr
     std::chrono::steady_clock::time_point t_batch;
     double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_batch).count(); }
+    int coders_wanted = 0;                   // coder threads of this context (set before they start: pinning needs it)
     std::vector<hipStream_t> copy_streams;   // shared by the coder threads (device -> host chunk copies)
     size_t chunk_bins = kChunkBins;          // bins per lane per chunk (NBLIC_AMD_CHUNK_BINS shrinks it, for tests of the chunk boundaries)
     std::vector<CodedBuf> cbufs;
@@ -602,7 +605,41 @@ static int coder_take(const nblic_amd_ctx *c) {                  // call with c-
     return int(q < size_t(kMaxTake) ? q : size_t(kMaxTake));
 }
 
+// One logical CPU per physical core of the process's affinity mask (the lowest-numbered sibling that is allowed).
+// NBLIC_AMD_PIN=1 pins coder thread i to core i of the mask (when there are enough cores), so that two coders --
+// each a dependent chain per AVX-512 lane that keeps its core's vector unit busy by itself -- never share the SMT
+// siblings of one core.  Off by default: measured on the GPU box, alternating runs, 5712 / 5356 Mpx/s pinned against
+// 5642 / 5642 left to the scheduler -- a pinned thread cannot step aside when a driver or runtime thread is put on
+// its CPU, and under the box's CPU quota that costs as much as the pinning saves.
+static std::vector<int> primary_cpus() {
+    std::vector<int> out;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) != 0) return out;
+    std::vector<int> cores;
+    for (int cpu = 0; cpu < CPU_SETSIZE; cpu++) {
+        if (!CPU_ISSET(cpu, &set)) continue;
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+        int first = cpu;
+        if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &first) != 1) first = cpu; fclose(f); }
+        if (std::find(cores.begin(), cores.end(), first) == cores.end()) { cores.push_back(first); out.push_back(cpu); }
+    }
+    return out;
+}
+
 static void coder_main(nblic_amd_ctx *c, int index) {
+    {
+        static const std::vector<int> cpus = primary_cpus();
+        static const bool pin = getenv("NBLIC_AMD_PIN") && atoi(getenv("NBLIC_AMD_PIN")) != 0;
+        if (pin && c->coders_wanted > 1 && cpus.size() >= size_t(c->coders_wanted)) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            static std::atomic<unsigned> next_core{0};            // across contexts: a second context's threads take the next cores
+            CPU_SET(cpus[size_t(next_core++ % cpus.size())], &one);
+            pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+        }
+    }
     CoderThread t;
     if (!t.init(c->device, c->copy_streams[size_t(index) % c->copy_streams.size()])) c->failed = true;
     for (;;) {
@@ -1323,6 +1360,7 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     c->copy_streams.resize(size_t(n_copy));
     for (auto &cs : c->copy_streams)
         if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { cs = nullptr; nblic_amd_destroy(c); return nullptr; }
+    c->coders_wanted = n_coders;
     for (int i = 0; i < n_coders; i++) c->coders.emplace_back(coder_main, c, i);
     for (int i = 0; i < n_groups; i++) c->drivers.emplace_back(driver_main, c, i);
     c->submitter = std::thread(submitter_main, c);
