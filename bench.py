@@ -256,7 +256,7 @@ def main():
     in_flight = args.steps_in_flight or (4 if dev_packs else 2)
     if not args.overlap_steps:
         in_flight = 1
-    host_buffers = args.host_buffers or (min(B + 16, slots + 16 * coders + 32) + 64 * dev_packs)   # groups in flight + every thread's sixteen + a queue (+ the device coder's packs)
+    host_buffers = args.host_buffers or (min(B + 16, slots + 24 * coders + 32) + 64 * dev_packs)   # groups in flight + every thread's sixteen + a queue (+ the device coder's packs)
     ctx = pkg.Context(device=gpu, n_slots=slots, n_coders=coders, n_groups=max(1, min(args.groups, slots)),
                       n_host_buffers=host_buffers)
     ctx.enable_timing(not os.environ.get("NBLIC_BENCH_NO_STAGE_TIMING"))     # (experiment switch: what the per-stage events cost)
@@ -333,6 +333,27 @@ def main():
         dt = float(t.item())
 
     # ---- reporting (outside the timed region) ------------------------------------------------
+    if os.environ.get("NBLIC_BENCH_THREAD_CPU"):          # who used the rank's CPU share: CPU seconds per thread name since process start
+        by_name = {}
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open(f"/proc/self/task/{tid}/comm") as f:
+                    name = f.read().strip()
+                with open(f"/proc/self/task/{tid}/stat") as f:
+                    fields = f.read().rsplit(")", 1)[1].split()
+                u, sy = int(fields[11]) / tick, int(fields[12]) / tick
+            except (OSError, IndexError, ValueError):
+                continue
+            e = by_name.setdefault(name, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += u; e[2] += sy
+        for name, (cnt, u, sy) in sorted(by_name.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+            print(f"[bench] threads {name!r} x{cnt}: user {u:.1f} s, system {sy:.1f} s", file=sys.stderr)
+        try:
+            with open("/sys/fs/cgroup/cpu.stat") as f:
+                print("[bench] cgroup cpu.stat: " + " ".join(f.read().split()), file=sys.stderr)
+        except OSError:
+            pass
     lens = last["lens"]
     stage = ctx.stage_times()                         # summed over the group launches of the last step
     launches = max(1, ctx.last_launches())            # each kernel is launched once per group of images

@@ -144,7 +144,7 @@ struct CodedBuf { uint16_t *p = nullptr; size_t cap = 0; };        // device; on
 constexpr size_t kChunkBins = size_t(1) << 22;
 constexpr int kCopyStreams = 8;
 constexpr int kRingDepth = 2;                                      // ring slots per coder thread: the chunk being coded + the next one on its way
-constexpr int kMaxTake = 16;                                       // images one coder thread codes together (two AVX-512 packs)
+constexpr int kMaxTake = 24;                                       // images one coder thread codes together (three AVX-512 packs; NBLIC_AMD_MAX_TAKE=16: two)
 
 }  // namespace nblic
 // One submitted batch (nblic_amd_encode_batch_begin .. _end); `remaining` is guarded by ctx->fm.
@@ -221,6 +221,7 @@ struct nblic_amd_ctx {
     std::chrono::steady_clock::time_point t_batch;
     double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_batch).count(); }
     int coders_wanted = 0;                   // coder threads of this context (set before they start: pinning needs it)
+    int max_take = kMaxTake;                 // images a coder thread takes together: 24 = three AVX-512 packs (NBLIC_AMD_MAX_TAKE=16: two, for A/B runs)
     std::vector<hipStream_t> copy_streams;   // shared by the coder threads (device -> host chunk copies)
     size_t chunk_bins = kChunkBins;          // bins per lane per chunk (NBLIC_AMD_CHUNK_BINS shrinks it, for tests of the chunk boundaries)
     std::vector<CodedBuf> cbufs;
@@ -247,7 +248,7 @@ struct nblic_amd_ctx {
     long stage_launches = 0;
     double total_bins = 0, coder_s = 0;
     double pack_bins = 0, pack_s = 0;     // the part of the above coded in packs (2..16 images per thread)
-    double wait_s = 0;                    // of coder_s: waiting for bins to arrive from HBM
+    double wait_s = 0, issue_s = 0;       // of coder_s: waiting for bins to arrive from HBM / queueing the next chunk
     long takes[kMaxTake + 1] = {0};       // how many times a thread took k images together
     std::mutex stat_m;
     // Submission is asynchronous: _begin only queues the batch; the submitter thread hands its images to the groups
@@ -435,9 +436,9 @@ static bool launch_front_serial(nblic_amd_ctx *c, Group &g, const uint8_t *const
 // (Measured and rejected: letting this kernel store straight into the mapped host ring.  The
 // PCIe-bound waves crowd the encoder's own kernels off the GPU: 4.6 -> 2.4 Gpx/s.)
 struct InterleaveArgs { const uint16_t *src[kMaxTake]; uint32_t len[kMaxTake]; };
-__global__ void __launch_bounds__(256) k_pack_groups(InterleaveArgs a, uint64_t *__restrict__ rows, uint32_t n_words) {
+__global__ void __launch_bounds__(256) k_pack_groups(InterleaveArgs a, uint64_t *__restrict__ rows, uint32_t n_words, uint32_t lanes) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t lane = t & 15u, word = t >> 4;               // word = 13 * group + j
+    const uint32_t word = t / lanes, lane = t - word * lanes;   // word = 13 * group + j; lanes = 16 (a pack pair) or 24 (three packs)
     if (word >= n_words) return;
     const uint32_t g = word / uint32_t(kGroupWords), j = word - g * uint32_t(kGroupWords);
     const uint32_t pos = g * uint32_t(kGroupBins), len = a.len[lane];
@@ -475,9 +476,9 @@ struct CoderThread {
     uint16_t *ring = nullptr;
     uint64_t *d_rows = nullptr;                          // device: two halves of 13-bit groups (k_pack_groups' output)
     uint16_t *whole = nullptr; size_t whole_cap = 0;     // pinned; one whole QNBLIC image (its rANS runs last pixel first)
-    RangeX8 x8, x8b;
+    RangeX8 x8, x8b, x8c;
     RangeScalar x1;
-    double wait_s = 0;                                   // time spent waiting for chunks (reporting)
+    double wait_s = 0, issue_s = 0;                      // time spent waiting for chunks / inside the runtime calls that queue a chunk (reporting)
     bool init(int device, hipStream_t copy_stream) {
         HIP_OK(hipSetDevice(device));
         stream = copy_stream;
@@ -493,18 +494,20 @@ struct CoderThread {
     // The ring holds kRingDepth slots of ring_lanes x ring_chunk bins; it is sized by what the thread has actually been
     // asked to code (one lane for an image coded alone, sixteen for a pack pair; the chunk no longer than the longest
     // image) and only grows: a context that codes one small image through the drop-in entry points pins kilobytes,
-    // the bench's threads end up at 2 x 16 x 4 Mbin x 2 B = 256 MB each.
+    // the bench's threads end up at 2 x 24 x 4 Mbin x 1.625 B = 327 MB each.
     size_t ring_lanes = 0, ring_chunk = 0, rows_cap = 0;
+    // 16-bit words per ring slot: a lone image's chunk as it is, or the 13-bit groups of ring_lanes lanes
+    size_t slot_words() const { return ring_lanes > 1 ? group_words(ring_chunk, ring_lanes) * 4 : ring_chunk; }
     bool ensure_ring(size_t lanes, size_t chunk, bool need_rows) {
         chunk = (chunk + 4095) & ~size_t(4095);
         if (lanes > ring_lanes || chunk > ring_chunk) {
             const size_t nl = lanes > ring_lanes ? lanes : ring_lanes, nc = chunk > ring_chunk ? chunk : ring_chunk;
             locked_free(ring);
-            ring = locked_alloc(kRingDepth * nl * nc);
-            if (!ring) { ring_lanes = ring_chunk = 0; fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
             ring_lanes = nl; ring_chunk = nc;
+            ring = locked_alloc(kRingDepth * slot_words());
+            if (!ring) { ring_lanes = ring_chunk = 0; fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
         }
-        const size_t want_rows = need_rows ? kRingDepth * group_words(ring_chunk) : 0;
+        const size_t want_rows = need_rows ? kRingDepth * group_words(ring_chunk, ring_lanes) : 0;
         if (want_rows > rows_cap) {
             if (d_rows) hipFree(d_rows);
             d_rows = nullptr; rows_cap = 0;
@@ -513,9 +516,9 @@ struct CoderThread {
         }
         return true;
     }
-    uint16_t *slot(size_t chunk, int lane) { return ring + (size_t(chunk % kRingDepth) * ring_lanes + size_t(lane)) * ring_chunk; }
-    uint64_t *rows(size_t chunk) { return reinterpret_cast<uint64_t *>(ring) + size_t(chunk % kRingDepth) * group_words(ring_chunk); }   // inside the bytes of the sixteen lanes' slots (26 of 32 bytes per bin column)
-    uint64_t *dev_rows(size_t chunk) { return d_rows + size_t(chunk % kRingDepth) * group_words(ring_chunk); }
+    uint16_t *slot(size_t chunk) { return ring + size_t(chunk % kRingDepth) * slot_words(); }            // a lone image's chunk
+    uint64_t *rows(size_t chunk) { return reinterpret_cast<uint64_t *>(slot(chunk)); }
+    uint64_t *dev_rows(size_t chunk) { return d_rows + size_t(chunk % kRingDepth) * group_words(ring_chunk, ring_lanes); }
 };
 
 // Streams `take` images' bins from HBM and codes them: one image with the scalar coder, up to
@@ -525,17 +528,22 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
                           const size_t *caps, size_t *lens, size_t chunk_bins) {
     size_t n_max = 0;
     for (int k = 0; k < take; k++) n_max = n[k] > n_max ? n[k] : n_max;
-    if (!t.ensure_ring(take > 1 ? size_t(kMaxTake) : 1, n_max < chunk_bins ? n_max + 4 : chunk_bins, take > 1)) return false;
+    // More than one image: AVX-512 packs in lock-step -- a lone pack is bound by the latency of its own dependent
+    // chain, a second one rides along almost for free, a third on what the core's ports have left (+20 % bins per
+    // CPU-second on the records of real frames, and the rank's CPU quota is what bounds the pipeline).  Up to sixteen
+    // images make two packs (16 lanes per word-row), more make three (24 lanes); the images are dealt to the packs
+    // in order, as evenly as they go: pack p owns lanes 8p .. 8p + count_p - 1.
+    const int n_packs = take > 16 ? 3 : (take > 1 ? 2 : 0);
+    const size_t lanes = size_t(8 * n_packs);
+    int pack_n[3] = {0, 0, 0}, pack_first[3] = {0, 0, 0};
+    for (int p = 0, at = 0; p < n_packs; p++) { pack_n[p] = take / n_packs + (p < take % n_packs ? 1 : 0); pack_first[p] = at; at += pack_n[p]; }
+    if (!t.ensure_ring(take > 1 ? lanes : 1, n_max < chunk_bins ? n_max + 4 : chunk_bins, take > 1)) return false;
     const size_t chunks = (n_max + chunk_bins - 1) / chunk_bins;                     // chunk_bins <= kChunkBins, the ring's slot size
     auto chunk_len = [&](size_t c, int k) { const size_t off = c * chunk_bins; return off >= n[k] ? size_t(0) : (n[k] - off < chunk_bins ? n[k] - off : chunk_bins); };
-    // two packs in lock-step whenever there is more than one image: a lone pack is bound by the
-    // latency of its own dependent chain, a second one rides along almost for free.  Pack a takes
-    // the first half of the images (lanes 0..), pack b the rest (lanes 8..).
-    const int na = take > 1 ? (take + 1) / 2 : 0, nb = take > 1 ? take - na : 0;
-    auto lane_of = [&](int k) { return k < na ? k : 8 + (k - na); };
+    auto lane_of = [&](int k) { int p = 0; while (p + 1 < n_packs && k >= pack_first[p + 1]) p++; return 8 * p + (k - pack_first[p]); };
     auto issue = [&](size_t c) -> bool {
         if (take == 1) {                                      // one image: its bins as they are, for the scalar coder
-            HIP_OK(hipMemcpyAsync(t.slot(c, 0), dev[0] + c * chunk_bins, chunk_len(c, 0) * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
+            HIP_OK(hipMemcpyAsync(t.slot(c), dev[0] + c * chunk_bins, chunk_len(c, 0) * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
         } else {                                              // a pack pair: interleaved on the GPU, one copy
             InterleaveArgs a{};
             size_t longest = 0;
@@ -551,35 +559,40 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
             uint64_t *d = t.dev_rows(c);
             static const int feed_dbg = getenv("NBLIC_AMD_DBG") ? atoi(getenv("NBLIC_AMD_DBG")) : 0;      // measurement aids (with & 128): & 512 no pack kernel, & 1024 no copy
             if (n_groups) {
-                if (!(feed_dbg & 512)) hipLaunchKernelGGL(k_pack_groups, dim3((n_groups * uint32_t(kGroupWords) * 16u + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_groups * uint32_t(kGroupWords));
+                if (!(feed_dbg & 512)) hipLaunchKernelGGL(k_pack_groups, dim3((n_groups * uint32_t(kGroupWords) * uint32_t(lanes) + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_groups * uint32_t(kGroupWords), uint32_t(lanes));
                 HIP_OK(hipGetLastError());
                 // (In this pipeline the runtime performs the copy with its blit kernel -- four 32 MB dispatches per 128 MB chunk --
                 // whatever was tried: ring from hipHostMalloc instead of hipHostRegister, 2 / 4 / 8 copy streams, the copy cut
                 // into 8 or 16 MB pieces; the same copy from a bare test program goes through SDMA.  DESIGN.md section 4.)
-                if (!(feed_dbg & 1024)) HIP_OK(hipMemcpyAsync(t.rows(c), d, group_words(longest) * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
+                if (!(feed_dbg & 1024)) HIP_OK(hipMemcpyAsync(t.rows(c), d, group_words(longest, lanes) * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
             }
         }
         HIP_OK(hipEventRecord(t.ev[c % kRingDepth], t.stream));
         return true;
     };
-    if (take > 1) { t.x8.begin(na, dst, caps); t.x8b.begin(nb, dst + na, caps + na); }
+    RangeX8 *const packs[3] = {&t.x8, &t.x8b, &t.x8c};
+    if (take > 1) { for (int p = 0; p < n_packs; p++) packs[p]->begin(pack_n[p], dst + pack_first[p], caps + pack_first[p]); }
     else t.x1.begin(dst[0], caps[0]);
     for (size_t c = 0; c + 1 < size_t(kRingDepth) && c < chunks; c++) if (!issue(c)) return false;
     for (size_t c = 0; c < chunks; c++) {
+        auto i0 = std::chrono::steady_clock::now();
         if (c + kRingDepth - 1 < chunks && !issue(c + kRingDepth - 1)) return false;      // its ring slot was consumed one chunk ago
         auto w0 = std::chrono::steady_clock::now();
+        t.issue_s += std::chrono::duration<double>(w0 - i0).count();
         HIP_OK(hipEventSynchronize(t.ev[c % kRingDepth]));
         t.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         if (take > 1) {
             size_t len[kMaxTake] = {0};
             for (int k = 0; k < take; k++) len[lane_of(k)] = chunk_len(c, k);
             static const bool feed_only = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 128);   // measurement aid: bins reach the host but are not coded
-            if (!feed_only) feed_pair_groups(t.x8, t.x8b, t.rows(c), len);
+            if (feed_only) {}
+            else if (n_packs == 3) feed_triple_groups(t.x8, t.x8b, t.x8c, t.rows(c), len);
+            else feed_pair_groups(t.x8, t.x8b, t.rows(c), len);
         } else {
-            t.x1.feed(t.slot(c, 0), chunk_len(c, 0));
+            t.x1.feed(t.slot(c), chunk_len(c, 0));
         }
     }
-    if (take > 1) { t.x8.end(lens); t.x8b.end(lens + na); }
+    if (take > 1) { for (int p = 0; p < n_packs; p++) packs[p]->end(lens + pack_first[p]); }
     else lens[0] = t.x1.finish();
     return true;
 }
@@ -601,8 +614,9 @@ static int coder_take(const nblic_amd_ctx *c) {                  // call with c-
     if (c->ready.front().kind == 1 || !c->simd) return 1;
     const size_t left = q + size_t(c->batch_to_come), threads = c->coders.size();
     if (left <= 2 * threads) return 1;                           // two rounds of singles beat one small pack
-    if (q < size_t(kMaxTake) && c->batch_to_come > 0 && left >= 4 * threads && c->idle_coders <= 1) return 0;   // mid-batch, every other thread busy: wait (~30 ms) for a full pack
-    return int(q < size_t(kMaxTake) ? q : size_t(kMaxTake));
+    const size_t full = size_t(c->max_take);
+    if (q < full && c->batch_to_come > 0 && left >= 4 * threads && c->idle_coders <= 1) return 0;   // mid-batch, every other thread busy: wait (~30-45 ms) for full packs
+    return int(q < full ? q : full);
 }
 
 // One logical CPU per physical core of the process's affinity mask (the lowest-numbered sibling that is allowed).
@@ -629,10 +643,17 @@ static std::vector<int> primary_cpus() {
 }
 
 static void coder_main(nblic_amd_ctx *c, int index) {
+    pthread_setname_np(pthread_self(), "nblic-coder");         // (thread names: who uses the rank's CPU share, tools/thread_cpu.py)
     {
         static const std::vector<int> cpus = primary_cpus();
         static const bool pin = getenv("NBLIC_AMD_PIN") && atoi(getenv("NBLIC_AMD_PIN")) != 0;
-        if (pin && c->coders_wanted > 1 && cpus.size() >= size_t(c->coders_wanted)) {
+        static const int pin_raw = getenv("NBLIC_AMD_PIN") ? atoi(getenv("NBLIC_AMD_PIN")) : 0;
+        if (pin_raw >= 100) {                                     // experiment: coder i on logical CPU (pin_raw - 100) + i, whatever the process's mask
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(pin_raw - 100 + index, &one);
+            pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+        } else if (pin && c->coders_wanted > 1 && cpus.size() >= size_t(c->coders_wanted)) {
             cpu_set_t one;
             CPU_ZERO(&one);
             static std::atomic<unsigned> next_core{0};            // across contexts: a second context's threads take the next cores
@@ -707,7 +728,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
         }
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (c->trace) fprintf(stderr, "[trace] %.3f coder %d finished %d in %.3f s\n", c->now(), index, take, dt);
-        { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; if (take > 1) { c->pack_bins += bins; c->pack_s += dt; } c->wait_s += t.wait_s; t.wait_s = 0; c->takes[take]++; }
+        { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; if (take > 1) { c->pack_bins += bins; c->pack_s += dt; } c->wait_s += t.wait_s; t.wait_s = 0; c->issue_s += t.issue_s; t.issue_s = 0; c->takes[take]++; }
         {
             std::lock_guard<std::mutex> l(c->fm);
             for (int k = 0; k < take; k++) { c->free_cbufs.push_back(im[k].cb); if (im[k].batch) im[k].batch->remaining -= 1; }
@@ -736,6 +757,7 @@ static int dev_take(const nblic_amd_ctx *c) {                  // call with c->r
 }
 
 static void dev_coder_main(nblic_amd_ctx *c, int index) {
+    pthread_setname_np(pthread_self(), "nblic-devcoder");
     (void)index;
     hipStream_t st = nullptr;
     hipEvent_t done = nullptr;
@@ -884,6 +906,7 @@ static void release_group(nblic_amd_ctx *c, int id) {
 static bool launch_q(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, bool on_device);
 
 static void driver_main(nblic_amd_ctx *c, int id) {
+    pthread_setname_np(pthread_self(), "nblic-driver");
     Group &g = c->groups[size_t(id)];
     if (hipSetDevice(c->device) != hipSuccess) fprintf(stderr, "[nblic_amd] driver thread: cannot select device %d\n", c->device);
     for (;;) {
@@ -936,7 +959,7 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
     if (idle) {                                                   // nothing outstanding: start the reporting afresh
         for (auto &v : c->stage_ms) v = 0;
         c->stage_launches = 0;
-        c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; for (auto &v : c->takes) v = 0;
+        c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; c->issue_s = 0; for (auto &v : c->takes) v = 0;
         c->dev_bins = 0; c->dev_packs = 0; c->dev_images = 0;
         c->failed = false;
         c->t_batch = std::chrono::steady_clock::now();
@@ -987,6 +1010,7 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
 }
 
 static void submitter_main(nblic_amd_ctx *c) {
+    pthread_setname_np(pthread_self(), "nblic-submit");
     if (hipSetDevice(c->device) != hipSuccess) c->failed = true;
     for (;;) {
         nblic_amd_ctx::SubmitItem it;
@@ -1020,9 +1044,13 @@ static void report_coders(nblic_amd_ctx *c) {                        // NBLIC_AM
     fprintf(stderr, "[nblic_amd] coder: singles %.0f Mbins in %.2f thread-s (%.0f Mbins/s), packs %.0f Mbins in %.2f thread-s (%.0f Mbins/s)\n",
             (c->total_bins - c->pack_bins) / 1e6, c->coder_s - c->pack_s, (c->total_bins - c->pack_bins) / 1e6 / (c->coder_s - c->pack_s + 1e-9),
             c->pack_bins / 1e6, c->pack_s, c->pack_bins / 1e6 / (c->pack_s + 1e-9));
-    fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that waiting for chunks; takes of 1/2-7/8/9-15/16 images: %ld/%ld/%ld/%ld/%ld\n", c->wait_s, c->takes[1],
-            c->takes[2] + c->takes[3] + c->takes[4] + c->takes[5] + c->takes[6] + c->takes[7], c->takes[8],
-            c->takes[9] + c->takes[10] + c->takes[11] + c->takes[12] + c->takes[13] + c->takes[14] + c->takes[15], c->takes[16]);
+    fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that queueing chunks (runtime calls)\n", c->issue_s);
+    long t2 = 0, t9 = 0, t17 = 0;
+    for (int k = 2; k <= 7; k++) t2 += c->takes[k];
+    for (int k = 9; k <= 15; k++) t9 += c->takes[k];
+    for (int k = 17; k < kMaxTake; k++) t17 += c->takes[k];
+    fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that waiting for chunks; takes of 1/2-7/8/9-15/16/17-23/24 images: %ld/%ld/%ld/%ld/%ld/%ld/%ld\n", c->wait_s,
+            c->takes[1], t2, c->takes[8], t9, c->takes[16], t17, c->takes[kMaxTake]);
 }
 
 static bool encode_wait(nblic_amd_ctx *c, nblic_amd_batch *b) {
@@ -1278,29 +1306,33 @@ int nblic_amd_range_code_chunked(const uint16_t *const *coded, const size_t *n, 
         }
         return 0;
     }
-    // as in the coder threads: pack a takes the first half of the streams (lanes 0..), pack b the rest
-    // (lanes 8..), each chunk is laid out as 13-bit groups (here on the host, in the pipeline by
-    // k_pack_groups on the GPU) and fed through feed_pair_groups
-    RangeX8 a, b;
-    const int na = (count + 1) / 2;
-    a.begin(na, outs, caps);
-    b.begin(count - na, outs + na, caps + na);
-    const size_t rows_cap = group_words(chunk);
+    // as in the coder threads: two packs up to sixteen streams, three beyond (dealt in order, as evenly as they go;
+    // pack p owns lanes 8p ..), each chunk laid out as 13-bit groups (here on the host, in the pipeline by
+    // k_pack_groups on the GPU) and fed through feed_pair_groups / feed_triple_groups
+    RangeX8 x[3];
+    const int n_packs = count > 16 ? 3 : 2;
+    const size_t lanes = size_t(8 * n_packs);
+    int pack_n[3] = {0, 0, 0}, pack_first[3] = {0, 0, 0};
+    for (int p = 0, at = 0; p < n_packs; p++) { pack_n[p] = count / n_packs + (p < count % n_packs ? 1 : 0); pack_first[p] = at; at += pack_n[p]; }
+    for (int p = 0; p < n_packs; p++) x[p].begin(pack_n[p], outs + pack_first[p], caps + pack_first[p]);
+    const size_t rows_cap = group_words(chunk, lanes);
     uint64_t *rows = static_cast<uint64_t *>(aligned_alloc(64, (rows_cap * sizeof(uint64_t) + 63) & ~size_t(63)));
     if (!rows) return -1;
     for (size_t off = 0; off < n_max; off += chunk) {
-        size_t len[16] = {0};
+        size_t len[kMaxTake] = {0};
         memset(rows, 0, rows_cap * sizeof(uint64_t));
         for (int k = 0; k < count; k++) {
-            const int lane = k < na ? k : 8 + (k - na);
+            int p = 0;
+            while (p + 1 < n_packs && k >= pack_first[p + 1]) p++;
+            const int lane = 8 * p + (k - pack_first[p]);
             len[lane] = off >= n[k] ? 0 : (n[k] - off < chunk ? n[k] - off : chunk);
-            pack_groups_host(rows, lane, coded[k] + off, len[lane]);
+            pack_groups_host(rows, lane, coded[k] + off, len[lane], int(lanes));
         }
-        feed_pair_groups(a, b, rows, len);
+        if (n_packs == 3) feed_triple_groups(x[0], x[1], x[2], rows, len);
+        else feed_pair_groups(x[0], x[1], rows, len);
     }
     free(rows);
-    a.end(lens);
-    b.end(lens + na);
+    for (int p = 0; p < n_packs; p++) x[p].end(lens + pack_first[p]);
     return 0;
 }
 
@@ -1361,6 +1393,7 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     for (auto &cs : c->copy_streams)
         if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { cs = nullptr; nblic_amd_destroy(c); return nullptr; }
     c->coders_wanted = n_coders;
+    if (const char *mt = getenv("NBLIC_AMD_MAX_TAKE")) { const int v = atoi(mt); if (v >= 2 && v <= kMaxTake) c->max_take = v; }
     for (int i = 0; i < n_coders; i++) c->coders.emplace_back(coder_main, c, i);
     for (int i = 0; i < n_groups; i++) c->drivers.emplace_back(driver_main, c, i);
     c->submitter = std::thread(submitter_main, c);

@@ -44,9 +44,10 @@ void feed_pair_rows(RangeX8 &a, RangeX8 &b, const uint64_t *rows, const size_t *
 // rows[(13 * g + j) * 16 + lane] = word j of the lane's group g (range_coder_x8.cpp, k_pack_groups in pipeline.hip)
 constexpr size_t kGroupBins = 64, kGroupWords = 13;
 constexpr uint32_t code13(uint32_t rec) { return (rec & 0xFFFu) | ((rec >> 3) & 0x1000u); }           // prob | bin << 12
-constexpr size_t group_words(size_t bins) { return (bins + kGroupBins - 1) / kGroupBins * kGroupWords * 16; }   // words of `bins` bins x sixteen lanes
-void feed_pair_groups(RangeX8 &a, RangeX8 &b, const uint64_t *rows, const size_t *len);
-void pack_groups_host(uint64_t *rows, int lane, const uint16_t *coded, size_t len);       // ORs one lane's records into zeroed rows (tests, the chunked self-check)
+constexpr size_t group_words(size_t bins, size_t lanes = 16) { return (bins + kGroupBins - 1) / kGroupBins * kGroupWords * lanes; }   // words of `bins` bins x `lanes` lanes
+void feed_pair_groups(RangeX8 &a, RangeX8 &b, const uint64_t *rows, const size_t *len);                    // 16 lanes
+void feed_triple_groups(RangeX8 &a, RangeX8 &b, RangeX8 &c, const uint64_t *rows, const size_t *len);      // 24 lanes: rows[(13 g + j) * 24 + lane]
+void pack_groups_host(uint64_t *rows, int lane, const uint16_t *coded, size_t len, int lanes = 16);   // ORs one lane's records into zeroed rows (tests, the chunked self-check)
 
 bool have_avx512();
 size_t range_code(const uint16_t *coded, size_t n, uint8_t *out, size_t cap);

@@ -89,16 +89,16 @@ def test_multi_stream_range_coder_matches_oracle(pkg, oracle):
 
 def test_chunked_resumable_coders_match_whole_stream_coding(pkg):
     """The coder threads feed the resumable coders chunk by chunk (scalar for one image, two
-    AVX-512 packs in lock-step for 2..16): any chunking, any mix of stream lengths (lanes drop
+    AVX-512 packs in lock-step for 2..16, three for 17..24): any chunking, any mix of stream lengths (lanes drop
     out as their stream ends, whole chunks may be empty for the short ones) must give the bytes
     of coding each stream whole."""
     rng = np.random.default_rng(11)
-    lengths = [5000, 1, 0, 777, 4096, 33, 2500, 9, 4999, 5001, 1234, 64, 63, 65, 3000, 17]
+    lengths = [5000, 1, 0, 777, 4096, 33, 2500, 9, 4999, 5001, 1234, 64, 63, 65, 3000, 17, 128, 5002, 0, 640, 2047, 4097, 52, 53]
     streams = [(rng.integers(1, 4096, n).astype(np.uint16) | (rng.integers(0, 2, n).astype(np.uint16) << 15)) for n in lengths]
     streams[4] = np.full(4096, 1 | (1 << 15), np.uint16)          # long runs of renormalisation
     streams[10] = np.full(1234, 4095, np.uint16)
     whole = [pkg.range_code(s) for s in streams]
-    for count in (1, 2, 3, 8, 9, 16):
+    for count in (1, 2, 3, 8, 9, 16, 17, 20, 23, 24):
         for chunk in (1, 7, 64, 1000, 4096, 10000):
             assert pkg.range_code_chunked(streams[:count], chunk) == whole[:count], (count, chunk)
     caps = [len(b) for b in whole]
