@@ -79,7 +79,7 @@ def profiled_traffic(kernel, images_per_launch):
         pass
     prof_ipl = float(meta.get("images_per_launch", 8))
     for row in csv.DictReader(open(files[-1])):
-        if row["kernel"].split("(")[0].split("::")[-1] == kernel:
+        if row["kernel"].split("(")[0].split("::")[-1].split("<")[0] == kernel:     # "void nblic::k_touch_scatter<false>(...)" -> k_touch_scatter
             col = next(c for c in row if c.startswith("hbm_MB_per_launch_corrected"))
             return int(float(row[col]) * 1048576 * images_per_launch / prof_ipl)
     return None
