@@ -19,6 +19,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -175,8 +176,14 @@ struct Slot {
 };
 
 // ---- a group of images that shares every kernel launch ---------------------------------------
+// What a driver thread sleeps on while its group's front half runs (a host function queued behind the front half
+// sets `ready`).  hipEventSynchronize is NOT a sleep here, whatever the event's flags say: measured, a driver burnt
+// 35 ms of CPU per 55 ms wait, 1.1 of the rank's 16 CPUs between the six of them -- quota the coder threads need.
+struct GroupWait { std::mutex m; std::condition_variable cv; bool ready = false; };
+
 struct Group {
     int id = 0;
+    std::unique_ptr<GroupWait> front = std::make_unique<GroupWait>();
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     E1Timers tm{};
@@ -249,6 +256,7 @@ struct nblic_amd_ctx {
     double total_bins = 0, coder_s = 0;
     double pack_bins = 0, pack_s = 0;     // the part of the above coded in packs (2..16 images per thread)
     double wait_s = 0, issue_s = 0;       // of coder_s: waiting for bins to arrive from HBM / queueing the next chunk
+    double driver_cpu_s = 0, driver_front_cpu_s = 0, driver_wait_cpu_s = 0; long driver_launches = 0;   // CPU time of the driver threads (reporting)
     long takes[kMaxTake + 1] = {0};       // how many times a thread took k images together
     std::mutex stat_m;
     // Submission is asynchronous: _begin only queues the batch; the submitter thread hands its images to the groups
@@ -567,6 +575,10 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
                 if (!(feed_dbg & 1024)) HIP_OK(hipMemcpyAsync(t.rows(c), d, group_words(longest, lanes) * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
             }
         }
+        // (Measured and rejected: sleeping on a condition variable woken by a host function behind the copy, as the
+        // driver threads do.  A host function holds its stream until it has run, two threads share a copy stream,
+        // and the chunks arrived so much later that the threads fell back to packs of eight: 6.1 -> 4.0 Gpx/s.
+        // The threads wait for chunks for < 10 % of their time, so what the event wait burns is small.)
         HIP_OK(hipEventRecord(t.ev[c % kRingDepth], t.stream));
         return true;
     };
@@ -865,10 +877,18 @@ static void on_group_done(void *vp) {
     c->fcv.notify_all();
 }
 
+static double thread_cpu_s();
 static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders, bool general = false) {
     // a BLOCKING wait: a spinning one per driver thread would take cores from the coder threads
-    HIP_OK(hipEventRecord(g.done, g.stream));
-    HIP_OK(hipEventSynchronize(g.done));
+    const double w0 = thread_cpu_s();
+    { std::lock_guard<std::mutex> l(g.front->m); g.front->ready = false; }
+    HIP_OK(hipLaunchHostFunc(g.stream, [](void *p) {
+        GroupWait *w = static_cast<GroupWait *>(p);
+        { std::lock_guard<std::mutex> l(w->m); w->ready = true; }
+        w->cv.notify_one();
+    }, g.front.get()));
+    { std::unique_lock<std::mutex> l(g.front->m); g.front->cv.wait(l, [&] { return g.front->ready; }); }
+    { std::lock_guard<std::mutex> l(c->stat_m); c->driver_wait_cpu_s += thread_cpu_s() - w0; }
     for (int k = 0; k < g.n_jobs; k++) {
         Slot &s = g.slots[size_t(k)];
         s.n_ev = g.h_totals[size_t(k) * kTotalsStride + 2];
@@ -905,6 +925,12 @@ static void release_group(nblic_amd_ctx *c, int id) {
 
 static bool launch_q(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, bool on_device);
 
+static double thread_cpu_s() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return double(ts.tv_sec) + 1e-9 * double(ts.tv_nsec);
+}
+
 static void driver_main(nblic_amd_ctx *c, int id) {
     pthread_setname_np(pthread_self(), "nblic-driver");
     Group &g = c->groups[size_t(id)];
@@ -916,9 +942,11 @@ static void driver_main(nblic_amd_ctx *c, int id) {
             if (!g.has_work) return;
             g.has_work = false;
         }
+        const double cpu0 = thread_cpu_s();
         const bool ok = g.kind == 0 ? (launch_front(c, g, g.imgs, g.on_device) && launch_back(c, g, true))
                       : g.kind == 2 ? (launch_front_serial(c, g, g.imgs, g.on_device) && launch_back(c, g, true, true))
                                     : launch_q(c, g, g.imgs, g.on_device);
+        { std::lock_guard<std::mutex> l(c->stat_m); c->driver_cpu_s += thread_cpu_s() - cpu0; c->driver_launches++; }
         if (!ok) {
             c->failed = true;
             hipStreamSynchronize(g.stream);
@@ -959,7 +987,7 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
     if (idle) {                                                   // nothing outstanding: start the reporting afresh
         for (auto &v : c->stage_ms) v = 0;
         c->stage_launches = 0;
-        c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; c->issue_s = 0; for (auto &v : c->takes) v = 0;
+        c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; c->issue_s = 0; c->driver_cpu_s = 0; c->driver_wait_cpu_s = 0; c->driver_launches = 0; for (auto &v : c->takes) v = 0;
         c->dev_bins = 0; c->dev_packs = 0; c->dev_images = 0;
         c->failed = false;
         c->t_batch = std::chrono::steady_clock::now();
@@ -1045,6 +1073,8 @@ static void report_coders(nblic_amd_ctx *c) {                        // NBLIC_AM
             (c->total_bins - c->pack_bins) / 1e6, c->coder_s - c->pack_s, (c->total_bins - c->pack_bins) / 1e6 / (c->coder_s - c->pack_s + 1e-9),
             c->pack_bins / 1e6, c->pack_s, c->pack_bins / 1e6 / (c->pack_s + 1e-9));
     fprintf(stderr, "[nblic_amd] coder: %.2f thread-s of that queueing chunks (runtime calls)\n", c->issue_s);
+    fprintf(stderr, "[nblic_amd] drivers: %.2f CPU-s in %ld group launches (%.1f ms each), %.2f CPU-s of that inside the wait for the front half\n",
+            c->driver_cpu_s, c->driver_launches, 1e3 * c->driver_cpu_s / double(c->driver_launches ? c->driver_launches : 1), c->driver_wait_cpu_s);
     long t2 = 0, t9 = 0, t17 = 0;
     for (int k = 2; k <= 7; k++) t2 += c->takes[k];
     for (int k = 9; k <= 15; k++) t9 += c->takes[k];
