@@ -591,7 +591,14 @@ static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size
         if (c + kRingDepth - 1 < chunks && !issue(c + kRingDepth - 1)) return false;      // its ring slot was consumed one chunk ago
         auto w0 = std::chrono::steady_clock::now();
         t.issue_s += std::chrono::duration<double>(w0 - i0).count();
-        HIP_OK(hipEventSynchronize(t.ev[c % kRingDepth]));
+        // a sleeping poll: hipEventSynchronize spins through the wait (see GroupWait), and CPU time is what the rank is
+        // short of; a chunk is ~30 ms of coding, so 100 us of extra latency on its arrival is nothing
+        for (;;) {
+            const hipError_t q = hipEventQuery(t.ev[c % kRingDepth]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { fprintf(stderr, "[nblic_amd] HIP error: %s\n", hipGetErrorString(q)); return false; }
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
         t.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         if (take > 1) {
             size_t len[kMaxTake] = {0};
