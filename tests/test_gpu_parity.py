@@ -293,13 +293,13 @@ def test_size_limits(pkg, gpu_ctx):
 
 @pytest.mark.gpu
 def test_sixteen_image_packs_and_chunked_streaming(pkg, oracle):
-    """Many images, few coder threads: the coder threads take full 16-image packs (two AVX-512
-    registers in lock-step), stream each image's bins from HBM in chunks (256 Kbin here, so the images
-    span up to a dozen chunks and all end at different bins) and wait for packs to fill mid-batch.
-    Every stream must still be the oracle's, byte for byte."""
+    """Many images, few coder threads: the coder threads take full 24-image sets (three AVX-512
+    registers in lock-step; two for what is left at the end), stream each image's bins from HBM in chunks
+    (256 Kbin here, so the images span up to a dozen chunks and all end at different bins) and wait for
+    packs to fill mid-batch.  Every stream must still be the oracle's, byte for byte."""
     rng = np.random.default_rng(3)
     imgs = []
-    for k in range(44):
+    for k in range(62):
         h, w = int(rng.integers(200, 760)), int(rng.integers(200, 900))
         imgs.append(inputs.make(inputs.CONTENTS[k % len(inputs.CONTENTS)], h, w) if k % 4 else inputs.syn1(h, w, seed=k + 1))
     import os
