@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--steps-in-flight", type=int, default=0, help="steps submitted ahead of the one being collected (0 = 4 with the device coder, else 2)")
     ap.add_argument("--device-min-outstanding", type=int, default=-1, help="images that must be unfinished for the device coder to take a pack (-1 = 2.8 x batch: its seconds of latency never become the tail of the run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-timing", choices=("roofline", "all", "off"), default="roofline",
+                    help="HIP events around k_touch_scatter and k_predict only (default), around every stage, or none")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 path be rehearsed with every rank on one GPU")
     ap.add_argument("--node-gpus", type=int, default=8, help="GPUs the host is shared between: a rank confines itself (threads and all) to 1/NODE_GPUS of the host's cores, both SMT siblings of each; 0 = no confinement")
     ap.add_argument("--launch-check", action="store_true", help="no GPU work: every rank joins a gloo group, rank 0 prints how many ranks it saw (tests the --gpus N launcher on a CPU-only box)")
@@ -259,7 +261,10 @@ def main():
     host_buffers = args.host_buffers or (min(B + 16, slots + 24 * coders + 32) + 64 * dev_packs)   # groups in flight + every thread's sixteen + a queue (+ the device coder's packs)
     ctx = pkg.Context(device=gpu, n_slots=slots, n_coders=coders, n_groups=max(1, min(args.groups, slots)),
                       n_host_buffers=host_buffers)
-    ctx.enable_timing(not os.environ.get("NBLIC_BENCH_NO_STAGE_TIMING"))     # (experiment switch: what the per-stage events cost)
+    # HIP events around the two kernels the line reports against a roof (k_touch_scatter, the dominant one by time per
+    # launch in every full-timing run and in profiles/*_kernel_stats.csv, and k_predict); --stage-timing all times all 31
+    # stages (2 % slower: thirty-two events per group launch), off none
+    ctx.enable_timing(0 if os.environ.get("NBLIC_BENCH_NO_STAGE_TIMING") else {"roofline": 2, "all": 1, "off": 0}[args.stage_timing])
     if dev_packs:
         ctx.set_device_coder(dev_packs, args.device_min_outstanding if args.device_min_outstanding >= 0 else int(2.8 * B))
     # streams land in one pinned slab (a slot per frame: worst case seen is 1.0025 B/px) so that the
@@ -359,7 +364,9 @@ def main():
     launches = max(1, ctx.last_launches())            # each kernel is launched once per group of images
     bins, coder_s = ctx.last_stats()
     dev_stats = ctx.device_coder_stats() if dev_packs else None
-    per_launch = {k: v / launches for k, v in stage.items() if k != "host_gap"}
+    per_launch = {k: v / launches for k, v in stage.items() if k != "host_gap" and (v > 0 or args.stage_timing == "all")}
+    if not per_launch:
+        per_launch = {"k_touch_scatter": 0.0}
     dom = max(per_launch, key=per_launch.get)
     imgs_per_launch = B * (args.steps if args.overlap_steps else 1) / launches   # the library's timers run over all overlapped steps
     alg_bytes = (H * W + float(np.mean(lens))) * imgs_per_launch   # 1 B/px read + L/N B/px written

@@ -152,7 +152,9 @@ void nblic_amd_set_max_pixels(nblic_amd_ctx *ctx, long max_pixels);
  * launch, on the stream the kernel runs on, summed over the batch's group launches (divide by
  * nblic_amd_last_launches() for the average launch duration).  Writes up to `cap` entries
  * of milliseconds into ms[] and matching static strings into names[]; returns the count.
- * Timing is recorded only after nblic_amd_enable_timing(ctx, 1).                           */
+ * Timing is recorded only after nblic_amd_enable_timing(ctx, 1) (every stage) or (ctx, 2): only
+ * k_predict and k_touch_scatter, the two stages the bench line reports against a roof -- thirty-two
+ * events per group launch cost the pipeline 2 % of its throughput, four do not; untimed stages read 0. */
 void nblic_amd_enable_timing(nblic_amd_ctx *ctx, int on);
 int nblic_amd_stage_times(nblic_amd_ctx *ctx, double *ms, const char **names, int cap);
 

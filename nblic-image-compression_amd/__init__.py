@@ -393,7 +393,8 @@ class Context:
         self.lib.nblic_amd_decode_batch(self.handle, k, sp, sl, op, caps, hs, ws, nn, ee, st)
         return [None if st[i] != 0 else (imgs[i][: hs[i], : ws[i]], nn[i], ee[i]) for i in range(k)]
 
-    def enable_timing(self, on: bool = True):
+    def enable_timing(self, on=True):
+        """0 / False off, 1 / True every stage, 2 only the stages the bench line reports against a roof."""
         self.lib.nblic_amd_enable_timing(self.handle, int(on))
 
     def set_max_pixels(self, n: int):

@@ -71,7 +71,8 @@ struct E1Job {
 // whole group of images.
 constexpr int kE1Kernels = 31;
 constexpr int kE1Marks = kE1Kernels + 1;
-struct E1Timers { hipEvent_t ev[kE1Marks]; };
+struct E1Timers { hipEvent_t ev[kE1Marks]; uint64_t mask = ~0ull; };     // mask: bit k = stage k is timed (events k and k + 1 are recorded)
+constexpr uint64_t kRooflineStages = (1ull << 1) | (1ull << 26);            // k_predict (S1) and k_touch_scatter: what the bench line's rooflines need
 static const char *const kE1StageNames[kE1Kernels] = {
     "k_init_state", "k_predict",
     "k_adr_count", "scan_reduce.adr", "scan_sums.adr", "scan_apply.adr", "k_adr_scatter",

@@ -1421,7 +1421,10 @@ static inline unsigned pad8(unsigned v) { return (v + 7u) & ~7u; }       // grid
 
 struct Marker {                       // records one event in front of every launch
     E1Timers *tm; hipStream_t s; int k;
-    void operator()() { if (tm) hipEventRecord(tm->ev[k], s); k++; }
+    void operator()() {
+        if (tm && (((tm->mask >> k) & 1ull) || (k > 0 && ((tm->mask >> (k - 1)) & 1ull)))) hipEventRecord(tm->ev[k], s);
+        k++;
+    }
 };
 
 template <int WHICH>

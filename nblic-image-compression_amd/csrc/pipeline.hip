@@ -218,6 +218,7 @@ struct nblic_amd_ctx {
     int device = 0;
     long max_px = kMaxPixels;
     bool timing = false;
+    uint64_t timing_mask = ~0ull;            // stages to time (kernels_e1.h E1Timers::mask)
     bool simd = false;                    // AVX-512 host: up to sixteen images per coder thread (two packs in lock-step)
     std::vector<Group> groups;
     std::mutex api;                       // one batch at a time per context
@@ -370,6 +371,7 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
         { static const int dbg = getenv("NBLIC_AMD_DBG") ? atoi(getenv("NBLIC_AMD_DBG")) : 0; J.dbg = dbg; }
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
+    g.tm.mask = c->timing_mask;
     e1_launch_front(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, c->timing ? &g.tm : nullptr);
     HIP_OK(hipMemcpyAsync(g.h_totals, g.d_totals, size_t(g.n_jobs) * kTotalsStride * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
     return true;
@@ -917,10 +919,12 @@ static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders, bool gener
 static void collect_timing(nblic_amd_ctx *c, Group &g) {
     if (!g.tm_pending) return;
     g.tm_pending = false;
-    if (hipEventSynchronize(g.tm.ev[kE1Kernels]) != hipSuccess) return;
+    int last = -1;
+    for (int k = 0; k < kE1Kernels; k++) if ((g.tm.mask >> k) & 1ull) last = k;
+    if (last < 0 || hipEventSynchronize(g.tm.ev[last + 1]) != hipSuccess) return;
     for (int k = 0; k < kE1Kernels; k++) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g.tm.ev[k], g.tm.ev[k + 1]) == hipSuccess) c->stage_ms[k] += ms;
+        if (((g.tm.mask >> k) & 1ull) && hipEventElapsedTime(&ms, g.tm.ev[k], g.tm.ev[k + 1]) == hipSuccess) c->stage_ms[k] += ms;
     }
     c->stage_launches++;
 }
@@ -1470,7 +1474,7 @@ void nblic_amd_set_max_pixels(nblic_amd_ctx *c, long max_pixels) {
     if (!c) c = default_ctx();                                               // NULL: the context behind the drop-in entry points
     if (c) c->max_px = max_pixels > 0 ? max_pixels : kMaxPixels;
 }
-void nblic_amd_enable_timing(nblic_amd_ctx *c, int on) { c->timing = on != 0; }
+void nblic_amd_enable_timing(nblic_amd_ctx *c, int on) { c->timing = on != 0; c->timing_mask = on == 2 ? kRooflineStages : ~0ull; }
 
 int nblic_amd_stage_times(nblic_amd_ctx *c, double *ms, const char **names, int cap) {
     int n = kE1Kernels;
