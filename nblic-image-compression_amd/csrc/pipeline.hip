@@ -636,7 +636,13 @@ static int coder_take(const nblic_amd_ctx *c) {                  // call with c-
     const size_t left = q + size_t(c->batch_to_come), threads = c->coders.size();
     if (left <= 2 * threads) return 1;                           // two rounds of singles beat one small pack
     const size_t full = size_t(c->max_take);
-    if (q < full && c->batch_to_come > 0 && left >= 4 * threads && c->idle_coders <= 1) return 0;   // mid-batch, every other thread busy: wait (~30-45 ms) for full packs
+    if (c->batch_to_come > 0 && left >= 4 * threads) {
+        // mid-batch: with every other thread busy wait (~30-45 ms) for a full set; with others idle too -- the start of a
+        // batch, or the GPU side not keeping up -- at least for two full packs: packs of four lanes cost twice the CPU
+        // time per bin, and CPU time is what the rank is short of
+        const size_t want = c->idle_coders <= 1 ? full : (full < 16 ? full : size_t(16));
+        if (q < want) return 0;
+    }
     return int(q < full ? q : full);
 }
 
