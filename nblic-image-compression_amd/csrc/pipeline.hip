@@ -3,9 +3,11 @@
 //
 // Images in flight are split into GROUPS that share every kernel launch (a driver thread and a HIP
 // stream per group).  A finished image's coded bins (u16 per bin) stay in an HBM buffer of a pool
-// until a coder thread streams them to the host chunk by chunk through its own small pinned ring
+// until a coder thread streams them to the host chunk by chunk (packed to 13 bits per bin and laid
+// out for its AVX-512 lanes by k_pack_groups, up to 24 images at a time) through its own pinned ring
 // and turns them into the byte-exact range-coder stream (NBLIC.c:552-586), while the GPU is already
-// working on the next groups.  Three kinds of group: staged -n0 -e1 encode, QNBLIC (effort 0) encode,
+// working on the next groups.  The rank's CPU share is what bounds the pipeline, so nothing here spins:
+// drivers sleep on a condition variable, coder threads poll for a chunk with 100 us sleeps.  Three kinds of group: staged -n0 -e1 encode, QNBLIC (effort 0) encode,
 // and the serial modes (near > 0, efforts 2/3), whose front half is the one-wave-per-image model
 // stage of serial_engine.hip and whose entropy stages are the same parallel kernels.
 #include <hip/hip_runtime.h>
