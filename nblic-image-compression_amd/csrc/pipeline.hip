@@ -146,7 +146,7 @@ struct CodedBuf { uint16_t *p = nullptr; size_t cap = 0; };        // device; on
 // next chunk 15-20 % of the time (4.7 Gpx/s), with 4 Mbin chunks 3 % (5.2 Gpx/s).
 constexpr size_t kChunkBins = size_t(1) << 22;
 constexpr int kCopyStreams = 8;
-constexpr int kRingDepth = 2;                                      // ring slots per coder thread: the chunk being coded + the next one on its way
+constexpr int kRingDepth = 3;                                      // ring slots per coder thread: the chunk being coded + the next two on their way (two slots: 6.14-6.30 Gpx/s, three: 6.35-6.38)
 constexpr int kMaxTake = 24;                                       // images one coder thread codes together (three AVX-512 packs; NBLIC_AMD_MAX_TAKE=16: two)
 
 }  // namespace nblic
@@ -506,7 +506,7 @@ struct CoderThread {
     // The ring holds kRingDepth slots of ring_lanes x ring_chunk bins; it is sized by what the thread has actually been
     // asked to code (one lane for an image coded alone, sixteen for a pack pair; the chunk no longer than the longest
     // image) and only grows: a context that codes one small image through the drop-in entry points pins kilobytes,
-    // the bench's threads end up at 2 x 24 x 4 Mbin x 1.625 B = 327 MB each.
+    // the bench's threads end up at 3 x 24 x 4 Mbin x 1.625 B = 491 MB each.
     size_t ring_lanes = 0, ring_chunk = 0, rows_cap = 0;
     // 16-bit words per ring slot: a lone image's chunk as it is, or the 13-bit groups of ring_lanes lanes
     size_t slot_words() const { return ring_lanes > 1 ? group_words(ring_chunk, ring_lanes) * 4 : ring_chunk; }
