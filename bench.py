@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--groups", type=int, default=6, help="launch groups the images in flight are split into")
     ap.add_argument("--host-buffers", type=int, default=0, help="coded-bin buffers in HBM between the GPU and the coder threads (0 = slots + 16*coders + 32)")
     ap.add_argument("--host-inputs", action="store_true", help="hand host buffers over (PCIe-inclusive rate)")
-    ap.add_argument("--gather-chunk", type=int, default=512, help="frames per exchange of the N>1 gather (bounds rank 0's receive buffers)")
+    ap.add_argument("--gather-chunk", type=int, default=256, help="frames per exchange of the N>1 gather (bounds rank 0's receive buffers: world x 2.3 GB at 256)")
     ap.add_argument("--no-overlap-steps", dest="overlap_steps", action="store_false",
                     help="collect every step before submitting the next (default: step k+1 is submitted with nblic_amd_encode_batch_begin "
                          "before step k is collected, as a continuous feed would; the pipeline's fill and drain are then paid once per "
@@ -277,7 +277,7 @@ def main():
         slabs.append(torch.empty((B, cap), dtype=torch.uint8, pin_memory=True))
         out_sets.append([slabs[-1][k].numpy() for k in range(B)])
     shapes = [(H, W)] * B
-    GATHER_CHUNK = max(1, args.gather_chunk)              # frames per exchange: bounds rank 0's receive buffers (world x 4.6 GB at 512)
+    GATHER_CHUNK = max(1, args.gather_chunk)              # frames per exchange: bounds rank 0's receive buffers (world x 2.3 GB at 256)
     dev_pack = torch.empty(min(B, GATHER_CHUNK) * cap, dtype=torch.uint8, device=comm_dev) if world > 1 else None
     ptrs = [f.ctypes.data for f in frames] if args.host_inputs else [d.data_ptr() for d in dev_frames]
     gather = None
