@@ -12,18 +12,20 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--modes", default="2:1,0:2,2:2,0:3")
+ap.add_argument("--groups", type=int, default=2, help="groups the images in flight are split into (each launches its own kernels on its own stream)")
 args = ap.parse_args()
 pkg = importlib.import_module("nblic-image-compression_amd")
 from oracle.oracle import Reference, syn1
 ref = Reference() if Reference.available() else None
 H = W = args.size
-ctx = pkg.Context(device=0, n_slots=max(2, args.batch), n_coders=8, n_groups=2, n_host_buffers=2 * args.batch + 16)
+ctx = pkg.Context(device=0, n_slots=max(2, args.batch), n_coders=8, n_groups=args.groups, n_host_buffers=2 * args.batch + 16)
 for mode in args.modes.split(","):
     near, effort = map(int, mode.split(":"))
     img = syn1(H, W, 1)
     ctx.encode_modes([img[:64, :64]], [near], [effort])                       # warm-up (allocations, code load)
     t0 = time.perf_counter(); s1, _ = ctx.encode_modes([img], [near], [effort]); t1 = time.perf_counter() - t0
     imgs = [syn1(H, W, k + 1) for k in range(args.batch)]
+    ctx.encode_modes(imgs, [near] * args.batch, [effort] * args.batch)        # the batch once untimed: every slot's statistics buffers are (re)allocated for this effort -- hipFree synchronises the device, which halved the timed rate
     t0 = time.perf_counter(); sb, _ = ctx.encode_modes(imgs, [near] * args.batch, [effort] * args.batch); tb = time.perf_counter() - t0
     t0 = time.perf_counter(); d1 = ctx.decode_batch(s1); td1 = time.perf_counter() - t0
     t0 = time.perf_counter(); db = ctx.decode_batch(sb); tdb = time.perf_counter() - t0
