@@ -85,13 +85,16 @@ int nblic_amd_encode_batch(nblic_amd_ctx *ctx, int n_images, const unsigned char
                            const int *heights, const int *widths, unsigned char *const *outs,
                            const size_t *out_caps, long *out_lens);
 
-/* The same batch in two halves, so that several batches can be in flight: _begin hands the images
- * to the GPU pipeline and returns as soon as the last of them has been handed over (it blocks only
- * while every group is busy); _end waits until every stream of THAT batch has been written and
- * returns 0 / -1 like nblic_amd_encode_batch.  While batch k drains through the host coder threads
- * (~0.8 s for the last 16-image packs) batch k+1 is already filling the GPU: a continuous feed
- * never sees the pipeline's fill and drain.  All argument arrays and buffers of a batch must stay
- * valid, and its outputs untouched, until its _end; batches may be ended in any order.        */
+/* The same batch in two halves, so that several batches can be in flight: _begin only QUEUES the
+ * batch and returns at once -- a submitter thread of the context hands its images to the GPU
+ * pipeline later (waiting while every group is busy), so the argument arrays are read AFTER _begin
+ * has returned; _end waits until every stream of THAT batch has been written and returns 0 / -1
+ * like nblic_amd_encode_batch: -1 when one of THIS batch's images failed (a failure in another
+ * batch in flight does not show here) or when the context itself is unusable.  While batch k
+ * drains through the host coder threads (~0.8 s for the last packs) batch k+1 is already filling
+ * the GPU: a continuous feed never sees the pipeline's fill and drain.  All argument arrays and
+ * buffers of a batch must stay valid, and its outputs untouched, until its _end; batches may be
+ * ended in any order.                                                                          */
 typedef struct nblic_amd_batch nblic_amd_batch;
 nblic_amd_batch *nblic_amd_encode_batch_begin(nblic_amd_ctx *ctx, int n_images, const unsigned char *const *imgs,
                                               int imgs_on_device, const int *heights, const int *widths,
@@ -147,6 +150,25 @@ void nblic_amd_device_coder_stats(nblic_amd_ctx *ctx, double *bins, long *packs,
  * BASELINE.json exceeds the reference's own limit, src/NBLIC.h:31).  0 restores the reference limit.
  * ctx == NULL addresses the context behind the drop-in entry points of section 1.                   */
 void nblic_amd_set_max_pixels(nblic_amd_ctx *ctx, long max_pixels);
+
+/* The raster-serial kernels (the model stage of near > 0 / efforts 2, 3 encodes, every decoder) are RESUMABLE:
+ * whatever their chain carries across a row boundary lives in a per-image state record on the device, a launch works
+ * on at most `rows` rows of every image, and the next launch picks up where it stopped -- so no kernel runs longer
+ * than a few seconds however large the image (config 5 of BASELINE.json is a 268 Mpixel frame at effort 3).
+ * rows > 0 fixes the rows per launch (tests use it to force many resumptions); 0 = sized automatically.
+ * ctx == NULL addresses the context behind the drop-in entry points.  nblic_amd_serial_launches: launches of the
+ * serial kernels since the context was created.                                                              */
+void nblic_amd_set_serial_rows(nblic_amd_ctx *ctx, int rows);
+long nblic_amd_serial_launches(nblic_amd_ctx *ctx);
+
+/* The reference's decoders take no stream length (src/NBLIC.h:72, src/QNBLIC.h:16).  NBLICdecompress / QNBLICdecompress
+ * therefore fetch the caller's stream ON DEMAND in steps of `bytes` (default 1 MiB, at least 4096): the decoder stops in
+ * front of a row when it is about to run short, the next step is copied in, it resumes.  No byte beyond the last one the
+ * decoder consumes plus one step is read, and each step is copied by the kernel (a pipe write), so a stream that ends
+ * right in front of an unmapped page is read exactly to its end instead of faulting.  ctx == NULL: the drop-in context.
+ * nblic_amd_last_fed_bytes: how many bytes the last drop-in decode read from the caller's buffer.                      */
+void nblic_amd_set_feed_chunk(nblic_amd_ctx *ctx, size_t bytes);
+long nblic_amd_last_fed_bytes(nblic_amd_ctx *ctx);
 
 /* Per-kernel device times of the LAST nblic_amd_encode_batch: one HIP event in front of every
  * launch, on the stream the kernel runs on, summed over the batch's group launches (divide by

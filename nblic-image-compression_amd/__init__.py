@@ -38,6 +38,7 @@ EXPORTS = (
     "nblic_amd_create", "nblic_amd_create_ex", "nblic_amd_destroy", "nblic_amd_encode_batch", "nblic_amd_encode_batch_begin", "nblic_amd_encode_batch_end", "nblic_amd_qencode_batch", "nblic_amd_set_max_pixels",
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
     "nblic_amd_encode_batch_modes", "nblic_amd_decode_batch", "nblic_amd_serial_selftest",
+    "nblic_amd_set_serial_rows", "nblic_amd_serial_launches", "nblic_amd_set_feed_chunk", "nblic_amd_last_fed_bytes",
     "nblic_amd_cli_main", "nblic_amd_cli_parse", "nblic_amd_read_gray", "nblic_amd_write_gray",
     "nblic_amd_set_device_coder", "nblic_amd_device_coder_stats",
     "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_range_code_chunked", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
@@ -115,6 +116,14 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_device_coder_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]
     lib.nblic_amd_set_max_pixels.restype = None
     lib.nblic_amd_set_max_pixels.argtypes = [C.c_void_p, C.c_long]
+    lib.nblic_amd_set_serial_rows.restype = None
+    lib.nblic_amd_set_serial_rows.argtypes = [C.c_void_p, C.c_int]
+    lib.nblic_amd_serial_launches.restype = C.c_long
+    lib.nblic_amd_serial_launches.argtypes = [C.c_void_p]
+    lib.nblic_amd_set_feed_chunk.restype = None
+    lib.nblic_amd_set_feed_chunk.argtypes = [C.c_void_p, C.c_size_t]
+    lib.nblic_amd_last_fed_bytes.restype = C.c_long
+    lib.nblic_amd_last_fed_bytes.argtypes = [C.c_void_p]
     lib.nblic_amd_enable_timing.restype = None
     lib.nblic_amd_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.nblic_amd_stage_times.restype = C.c_int
@@ -182,6 +191,25 @@ def decompress(stream: bytes) -> Optional[Tuple[np.ndarray, int, int]]:
     if rc != 0:
         return None
     return img[:hh.value, :ww.value], n.value, e.value
+
+
+def set_default_feed_chunk(n: int) -> None:
+    """Step in which the drop-in decoders fetch a stream of unknown length (``nblic_amd_set_feed_chunk(NULL, n)``)."""
+    load_library().nblic_amd_set_feed_chunk(None, n)
+
+
+def set_default_serial_rows(rows: int) -> None:
+    """Rows per launch of the resumable serial kernels behind the drop-in operators (0 = automatic)."""
+    load_library().nblic_amd_set_serial_rows(None, rows)
+
+
+def default_serial_launches() -> int:
+    return int(load_library().nblic_amd_serial_launches(None))
+
+
+def last_fed_bytes() -> int:
+    """Bytes the last drop-in decode read from the caller's stream (``nblic_amd_last_fed_bytes(NULL)``)."""
+    return int(load_library().nblic_amd_last_fed_bytes(None))
 
 
 def set_default_max_pixels(n: int) -> None:
@@ -399,6 +427,13 @@ class Context:
 
     def set_max_pixels(self, n: int):
         self.lib.nblic_amd_set_max_pixels(self.handle, n)
+
+    def set_serial_rows(self, rows: int):
+        """Rows per launch of the resumable serial kernels (``nblic_amd_set_serial_rows``); 0 = automatic."""
+        self.lib.nblic_amd_set_serial_rows(self.handle, rows)
+
+    def serial_launches(self) -> int:
+        return int(self.lib.nblic_amd_serial_launches(self.handle))
 
     def encode_ptrs(self, ptrs: Sequence[int], shapes: Sequence[Tuple[int, int]], on_device: bool,
                     outs: Optional[List[np.ndarray]] = None) -> Tuple[List[np.ndarray], np.ndarray]:

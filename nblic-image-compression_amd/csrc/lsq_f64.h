@@ -42,28 +42,28 @@ constexpr int kBiasInit = 8, kBiasMax = 4096, kBiasCoef = 21;
 LSQ_HD int order_of(int effort) { return effort == 2 ? 6 : (effort == 3 ? kMaxN : 0); }
 LSQ_HD int vec_len(int n) { return 1 + n + n * n; }     // [s | b(n) | A(n x n)], NBLIC.c:213-215
 
-// Sticky record of the magnitudes one solve has seen, kept as the HIGH WORDS of the largest |values|
-// (sign cleared): for power-of-two limits "high word below the limit's high word" is exactly
-// "|v| below the limit", it costs two 32-bit integer operations instead of a 64-bit float maximum, and an
-// infinity or a NaN reads as over the limit.  ok() false => redo the pixel with integers.
-LSQ_HD uint32_t magnitude_word(double v) {
+// Sticky record of the largest magnitudes one solve has seen: product / entry / quotient = max |v| so far, one
+// instruction per value on the device (v_max_f64 with |.| on both operands; the library fmax would wrap each operand
+// in a canonicalising maximum of its own).  A maximum drops NaNs, which is sound here: a NaN can only arise after a
+// zero pivot (0 * inf), the solve then reports "no solution" exactly as the reference does (NBLIC.c:118), and an
+// infinity still reads as over the limit.  ok() false => redo the pixel with integers.
+LSQ_HD double max_abs(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return uint32_t(__double2hiint(v)) & 0x7FFFFFFFu;
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 #else
-    uint64_t b;
-    memcpy(&b, &v, sizeof b);
-    return uint32_t(b >> 32) & 0x7FFFFFFFu;
+    return fmax(fabs(a), fabs(b));
 #endif
 }
-constexpr uint32_t pow2_word(int k) { return uint32_t(1023 + k) << 20; }
 struct Guard {
-    uint32_t product = 0, entry = 0, quotient = 0;
-    LSQ_HD void see_product(double v) { const uint32_t m = magnitude_word(v); product = m > product ? m : product; }
-    LSQ_HD void see_entry(double v) { const uint32_t m = magnitude_word(v); entry = m > entry ? m : entry; }
-    LSQ_HD void see_quotient(double v) { const uint32_t m = magnitude_word(v); quotient = m > quotient ? m : quotient; }
+    double product = 0.0, entry = 0.0, quotient = 0.0;
+    LSQ_HD void see_product(double v) { product = max_abs(product, v); }
+    LSQ_HD void see_entry(double v) { entry = max_abs(entry, v); }
+    LSQ_HD void see_quotient(double v) { quotient = max_abs(quotient, v); }
     // 2^62: beyond it the reference's int64 product may wrap; 2^44: entries stay exact and the pivot key (|v| * 256 + tag)
     // fits 53 bits; 2^46: an estimate this large may be off by more than one
-    LSQ_HD bool ok() const { return product < pow2_word(62) && entry < pow2_word(44) && quotient < pow2_word(46); }
+    LSQ_HD bool ok() const { return product < 4611686018427387904.0 && entry < 17592186044416.0 && quotient < 70368744177664.0; }
 };
 
 // ---- truncating division by estimate + exact remainder -------------------------------------------
@@ -85,13 +85,19 @@ LSQ_HD double recip_short(double d) {
 #endif
 }
 
-// +-1.0 with the sign of a * b
-LSQ_HD double unit_with_sign_of(double a, double b) {
+// The one-sided correction of an estimated quotient: +-1.0 (the sign of n * d) when the remainder r of the estimate
+// is still as large as the divisor, else 0.  On the device the select is spelled out (a compare into vcc and ONE
+// conditional move of a float unit, widened afterwards): left to itself the compiler turns the rare correction into
+// an exec-masked block around three integer operations -- two scalar instructions and a pipeline bubble per quotient,
+// forty-four times per pixel.
+LSQ_HD double fix_up(double r, double d, double n) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int hi = ((__double2hiint(a) ^ __double2hiint(b)) & int(0x80000000u)) | 0x3FF00000;
-    return __hiloint2double(hi, 0);
+    const int unit = ((__double2hiint(n) ^ __double2hiint(d)) & int(0x80000000u)) | 0x3F800000;      // +-1.0f
+    float c;
+    asm("v_cmp_ge_f64 vcc, |%1|, |%2|\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(c) : "v"(r), "v"(d), "v"(unit) : "vcc");
+    return double(c);
 #else
-    return copysign(1.0, a) * copysign(1.0, b);
+    return fabs(r) >= fabs(d) ? copysign(1.0, n) * copysign(1.0, d) : 0.0;
 #endif
 }
 
@@ -99,7 +105,7 @@ LSQ_HD double unit_with_sign_of(double a, double b) {
 LSQ_HD double div_trunc(double n, double d, double rs) {
     const double q0 = trunc(n * rs);
     const double r = fma(-q0, d, n);                     // exact; same sign as n, |r| < 2|d|
-    return q0 + (fabs(r) >= fabs(d) ? unit_with_sign_of(n, d) : 0.0);
+    return q0 + fix_up(r, d, n);
 }
 
 // trunc(a * b / d) with the product carried exactly as p + e (|a b| may exceed 2^53).
@@ -109,7 +115,7 @@ LSQ_HD double muldiv_trunc(double a, double b, double d, double rs, Guard &g) {
     const double q0 = trunc(p * rs);
     const double r = fma(-q0, d, p) + e;                 // exact remainder of the estimate
     g.see_product(p);
-    return q0 + (fabs(r) >= fabs(d) ? unit_with_sign_of(p, d) : 0.0);
+    return q0 + fix_up(r, d, p);
 }
 
 // (v * (ab-1) + ab/2) / ab, truncating (NBLIC.c:199, :273-279); |v| < 2^44
@@ -136,13 +142,13 @@ constexpr double kScaleB = 268435456.0;                  // 1 << (4 + FB1 + FB1)
 constexpr double kScaleA = 262144.0;                     // 1 << (4 + FB2 + FB1)
 
 // contribution of coefficient k to the Q12 prediction (NBLIC.c:233-236): (b*vn*4 + (d >> 1)) / d
-LSQ_HD double term(double b, int vn, double d, Guard &g) {
+LSQ_HD double term(double b, int vn, double d, double rs, Guard &g) {                  // rs = recip_short(d)
     const double n = fma(b, double(vn * (1 << kFb2)), floor(d * 0.5));
-    const double rs = recip_short(d);
     g.see_quotient(n * rs);
     g.see_entry(b);
     return div_trunc(n, d, rs);
 }
+LSQ_HD double term(double b, int vn, double d, Guard &g) { return term(b, vn, d, recip_short(d), g); }
 
 // the two candidate regularisation strengths around `bias` (NBLIC.c:837-842)
 LSQ_HD void bias_pair(int bias, int &b1, int &b2) {

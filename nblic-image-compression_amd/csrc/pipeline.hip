@@ -29,6 +29,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include "../../include/nblic_amd.h"
 #include "device_coder.h"
@@ -175,6 +176,7 @@ struct Slot {
     // serial modes: reconstruction (near > 0) and least-squares statistics (efforts 2/3)
     uint8_t *d_recon = nullptr; size_t recon_cap = 0;
     double *d_stats = nullptr; size_t stats_cap = 0;
+    SerialState *d_state = nullptr;   // what the model stage carries from launch to launch (serial_engine.h)
 };
 
 // ---- a group of images that shares every kernel launch ---------------------------------------
@@ -252,7 +254,7 @@ struct nblic_amd_ctx {
     std::mutex dm;
     std::condition_variable dcv;
     bool stop_drivers = false;
-    std::atomic<bool> failed{false};
+    std::atomic<bool> broken{false};         // a thread of the context could not set itself up (sticky); a failure of one image is recorded in ITS batch
     // reporting
     double stage_ms[kE1Kernels] = {0};
     long stage_launches = 0;
@@ -281,7 +283,12 @@ struct nblic_amd_ctx {
     // decode batches (nblic_amd_decode_batch): a stream of their own and grow-only device / pinned arenas
     hipStream_t dec_stream = nullptr;
     uint8_t *dec_arena = nullptr; size_t dec_arena_cap = 0;
-    SerialJob *dec_jobs = nullptr; int *dec_status = nullptr; int dec_jobs_cap = 0;
+    SerialJob *dec_jobs = nullptr; int dec_jobs_cap = 0;
+    int serial_rows = 0;                  // rows per launch of the serial kernels; 0 = sized for a few seconds per launch (nblic_amd_set_serial_rows)
+    long serial_launch_count = 0;         // launches of the serial model / decode kernels since the context was created (reporting, tests)
+    size_t feed_chunk = size_t(1) << 20;  // bytes per step in which the drop-in decoders fetch a stream of unknown length (nblic_amd_set_feed_chunk)
+    long fed_bytes = 0;                   // bytes the last drop-in decode read from the caller's stream
+    int feed_pipe[2] = {-1, -1};          // safe_copy: the kernel does the reading
 };
 
 namespace nblic {
@@ -311,6 +318,7 @@ static bool group_init(Group &g, int id, int n_slots, nblic_amd_ctx *c) {
         HIP_OK(hipMalloc((void **)&s.b.blk_base, 4097 * sizeof(uint32_t)));
         HIP_OK(hipMalloc((void **)&s.b.dbg_out, 4096 * sizeof(unsigned long long)));
         HIP_OK(hipMemset(s.b.dbg_out, 0, 4096 * sizeof(unsigned long long)));
+        HIP_OK(hipMalloc((void **)&s.d_state, kModelStateBytes));
     }
     return true;
 }
@@ -321,7 +329,7 @@ static void group_free(Group &g) {
         hipFree(s.b.pos3); hipFree(s.b.s3out); hipFree(s.b.z); hipFree(s.b.cnt); hipFree(s.b.ev_off); hipFree(s.b.table);
         hipFree(s.b.scan_sums); hipFree(s.b.ctx_state); hipFree(s.b.map_state); hipFree(s.b.cnt_state); hipFree(s.b.events);
         hipFree(s.b.tin); hipFree(s.b.tpos); hipFree(s.b.tout); hipFree(s.b.win_base); hipFree(s.b.win_recs); hipFree(s.b.blk_base); hipFree(s.b.dbg_out); hipFree(s.b.qhist); hipFree(s.b.blk_end); hipFree(s.b.blk_ok); hipFree(s.d_img);
-        hipFree(s.d_recon); hipFree(s.d_stats);
+        hipFree(s.d_recon); hipFree(s.d_stats); hipFree(s.d_state);
     }
     hipFree(g.d_jobs); hipFree(g.d_totals); hipFree(g.d_sjobs);
     if (g.h_sjobs) hipHostFree(g.h_sjobs);
@@ -395,7 +403,7 @@ static bool launch_front_serial(nblic_amd_ctx *c, Group &g, const uint8_t *const
             HIP_OK(hipMemcpyAsync(s.d_img, imgs[s.job], n, hipMemcpyHostToDevice, g.stream));
             s.b.img = s.d_img;
         }
-        const bool wide = 3 * ((s.w + 15) & ~15) > 140 * 1024;          // rows do not fit in LDS: taps come from the reconstruction in memory
+        const bool wide = !serial_model_rows_fit(s.w);                   // rows do not fit in LDS: taps come from the reconstruction in memory
         const bool want_recon = s.near > 0 || wide;
         if (want_recon && n > s.recon_cap) { if (!dev_alloc(s.d_recon, n)) return false; s.recon_cap = n; }
         const size_t st = stats_doubles(s.effort, s.w);
@@ -408,6 +416,8 @@ static bool launch_front_serial(nblic_amd_ctx *c, Group &g, const uint8_t *const
         Q = SerialJob{};
         Q.img = s.b.img; Q.recon = want_recon ? s.d_recon : nullptr; Q.rec1 = s.b.rec1; Q.pxs = s.b.pxs; Q.stats = s.d_stats;
         Q.h = s.h; Q.w = s.w; Q.near = s.near; Q.k_step = J.k_step; Q.effort = s.effort;
+        Q.state = s.d_state; Q.rows = serial_rows_per_launch(s.h, s.w, s.effort, c->serial_rows);
+        HIP_OK(hipMemsetAsync(s.d_state, 0, sizeof(SerialState), g.stream));               // a fresh image: row 0, running
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
     HIP_OK(hipMemcpyAsync(g.d_sjobs, g.h_sjobs, size_t(g.n_jobs) * sizeof(SerialJob), hipMemcpyHostToDevice, g.stream));
@@ -415,7 +425,13 @@ static bool launch_front_serial(nblic_amd_ctx *c, Group &g, const uint8_t *const
     for (int k0 = 0; k0 < g.n_jobs;) {
         int k1 = k0 + 1;
         while (k1 < g.n_jobs && g.slots[size_t(k1)].effort == g.slots[size_t(k0)].effort) k1++;
-        if (!serial_model_launch(g.d_sjobs + k0, g.h_sjobs + k0, k1 - k0, g.stream)) return false;
+        // an image is worked through `rows` rows per launch (its state record carries it from one to the next), so no
+        // kernel runs longer than a few seconds however large the image; images that are done return at once
+        int launches = 1;
+        for (int k = k0; k < k1; k++) launches = std::max(launches, serial_launches(g.h_sjobs[k].h, g.h_sjobs[k].rows));
+        for (int l = 0; l < launches; l++)
+            if (!serial_model_launch(g.d_sjobs + k0, g.h_sjobs + k0, k1 - k0, g.stream)) return false;
+        { std::lock_guard<std::mutex> sl(c->stat_m); c->serial_launch_count += launches; }
         k0 = k1;
     }
     for (int k = 0; k < g.n_jobs; k++) {                                 // the encoder leaves the reconstruction in the caller's plane (NBLIC.c:876)
@@ -691,7 +707,7 @@ static void coder_main(nblic_amd_ctx *c, int index) {
         }
     }
     CoderThread t;
-    if (!t.init(c->device, c->copy_streams[size_t(index) % c->copy_streams.size()])) c->failed = true;
+    if (!t.init(c->device, c->copy_streams[size_t(index) % c->copy_streams.size()])) c->broken = true;
     for (;;) {
         ReadyImage im[kMaxTake];
         int take = 0;
@@ -725,10 +741,8 @@ static void coder_main(nblic_amd_ctx *c, int index) {
                 const uint32_t *hist = reinterpret_cast<const uint32_t *>(t.whole + n_pad);
                 words_out = q_entropy_encode(reinterpret_cast<uint16_t *>(q.outs[q.job]), q.caps[q.job], q.h, q.w, t.whole, hist);
                 if (words_out < 0) fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu words is too small\n", q.job, q.caps[q.job]);
-            } else {
-                c->failed = true;
             }
-            q.lens[q.job] = words_out;
+            q.lens[q.job] = words_out;                           // -1: the batch this image belongs to reports the failure
             { std::lock_guard<std::mutex> l(c->fm); c->free_cbufs.push_back(q.cb); c->coding -= 1; if (q.batch) q.batch->remaining -= 1; }
             c->fcv.notify_all();
             continue;
@@ -747,7 +761,6 @@ static void coder_main(nblic_amd_ctx *c, int index) {
         static const bool skip_coding = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 16);   // measurement aid: device side alone
         if (skip_coding) { for (int k = 0; k < take; k++) lens[k] = 0; }
         else if (!code_streamed(t, src, n, take, dst, caps, lens, c->chunk_bins)) {
-            c->failed = true;
             hipDeviceSynchronize();
             for (int k = 0; k < take; k++) lens[k] = SIZE_MAX;
         }
@@ -799,7 +812,7 @@ static void dev_coder_main(nblic_amd_ctx *c, int index) {
               hipMalloc((void **)&d_jobs, kDevPack * sizeof(RcJob)) == hipSuccess &&
               hipHostMalloc((void **)&h_lens, kDevPack * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&d_lens, kDevPack * sizeof(uint32_t)) == hipSuccess;
-    if (!ok) c->failed = true;
+    if (!ok) c->broken = true;
     for (;;) {
         ReadyImage im[kDevPack];
         int take = 0;
@@ -840,7 +853,7 @@ static void dev_coder_main(nblic_amd_ctx *c, int index) {
             im[k].lens[im[k].job] = len;
         }
         if (hipStreamSynchronize(st) != hipSuccess) good = false;
-        if (!good) { c->failed = true; for (int k = 0; k < take; k++) im[k].lens[im[k].job] = -1; }
+        if (!good) { for (int k = 0; k < take; k++) im[k].lens[im[k].job] = -1; }
         { std::lock_guard<std::mutex> l(c->stat_m); c->dev_bins += bins; c->dev_packs++; c->dev_images += take; }
         {
             std::lock_guard<std::mutex> l(c->fm);
@@ -904,7 +917,15 @@ static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders, bool gener
         { std::lock_guard<std::mutex> l(w->m); w->ready = true; }
         w->cv.notify_one();
     }, g.front.get()));
-    { std::unique_lock<std::mutex> l(g.front->m); g.front->cv.wait(l, [&] { return g.front->ready; }); }
+    {   // a sleep, but not an unconditional one: if the stream has faulted the host function may never run
+        std::unique_lock<std::mutex> l(g.front->m);
+        while (!g.front->cv.wait_for(l, std::chrono::milliseconds(50), [&] { return g.front->ready; })) {
+            l.unlock();
+            const hipError_t q = hipStreamQuery(g.stream);
+            l.lock();
+            if (q != hipSuccess && q != hipErrorNotReady) { fprintf(stderr, "[nblic_amd] group %d: %s while waiting for the front half\n", g.id, hipGetErrorString(q)); return false; }
+        }
+    }
     { std::lock_guard<std::mutex> l(c->stat_m); c->driver_wait_cpu_s += thread_cpu_s() - w0; }
     for (int k = 0; k < g.n_jobs; k++) {
         Slot &s = g.slots[size_t(k)];
@@ -967,7 +988,6 @@ static void driver_main(nblic_amd_ctx *c, int id) {
                                     : launch_q(c, g, g.imgs, g.on_device);
         { std::lock_guard<std::mutex> l(c->stat_m); c->driver_cpu_s += thread_cpu_s() - cpu0; c->driver_launches++; }
         if (!ok) {
-            c->failed = true;
             hipStreamSynchronize(g.stream);
             {   // coded-bin buffers the failed launch had already taken go back to the pool
                 std::lock_guard<std::mutex> l(c->fm);
@@ -1008,7 +1028,6 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
         c->stage_launches = 0;
         c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; c->issue_s = 0; c->driver_cpu_s = 0; c->driver_wait_cpu_s = 0; c->driver_launches = 0; for (auto &v : c->takes) v = 0;
         c->dev_bins = 0; c->dev_packs = 0; c->dev_images = 0;
-        c->failed = false;
         c->t_batch = std::chrono::steady_clock::now();
         c->trace = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 64);
     }
@@ -1058,7 +1077,7 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
 
 static void submitter_main(nblic_amd_ctx *c) {
     pthread_setname_np(pthread_self(), "nblic-submit");
-    if (hipSetDevice(c->device) != hipSuccess) c->failed = true;
+    if (hipSetDevice(c->device) != hipSuccess) c->broken = true;
     for (;;) {
         nblic_amd_ctx::SubmitItem it;
         {
@@ -1122,7 +1141,7 @@ static bool encode_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const *i
     { std::lock_guard<std::mutex> l(c->fm); idle = c->coding == 0; }
     if (idle) for (auto &g : c->groups) collect_timing(c, g);
     report_coders(c);
-    return ok && !c->failed;
+    return ok && !c->broken;
 }
 
 // ---- QNBLIC (effort 0): model on the GPU, entropy stage on a coder thread ---------------------
@@ -1161,7 +1180,6 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
                            const int *ws, uint16_t *const *outs, const size_t *caps_words, long *len_words) {
     if (hipSetDevice(c->device) != hipSuccess) return false;
     bool ok = true;
-    c->failed = false;
     for (int k = 0; k < n_images; k++) len_words[k] = -1;
     { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come += n_images; }
     int next = 0;
@@ -1190,119 +1208,251 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
         c->fcv.wait(l, [c] { return c->coding == 0; });
     }
     for (int k = 0; k < n_images; k++) if (len_words[k] < 0) ok = false;
-    return ok && !c->failed;
+    return ok && !c->broken;
 }
 
 // ---- decoders: every stream of a batch side by side, one wave per image (serial_engine.hip) -----
 long q_decode_tables(const uint16_t *in, size_t n_words, int *h, int *w, uint32_t *freq, uint32_t *start, uint8_t *slot);
 
-struct DecodeItem { int k, h, w, near, k_step, effort, kind; size_t len; };      // kind 0 NBLIC, 1 QNBLIC
+struct DecodeItem { int k, h, w, near, k_step, effort, kind; size_t len; long q_pos; int qtab; };      // kind 0 NBLIC, 1 QNBLIC; q_pos: first rANS word; qtab: which parsed table set
 
-// Parses and validates the headers (NBLIC.c:698-745, QNBLIC.c:475-486), uploads the streams, launches one
-// kernel per (codec, effort) class present and copies the planes back.  status[k] = 0 / -1 per image.
+constexpr size_t kQTab = 2 * 12 * 256 * sizeof(uint32_t) + size_t(12) * 32768;              // QNBLIC: frequencies, cumulative starts, slot -> symbol
+static size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
+
+// Header of a stream of which `len` bytes are in hand (NBLIC.c:698-745, QNBLIC.c:475-486).  0 = not a stream this
+// library decodes (or refused: size, parameters), 1 = fields filled in.
+static int parse_stream_header(const unsigned char *p, size_t len, long max_px, DecodeItem &it) {
+    if (len >= size_t(kHeaderBytes) && memcmp(p, "NBLIC0.3", 8) == 0) {
+        const int n_channel = p[8];
+        it.kind = 0; it.h = (p[9] << 8) | p[10]; it.w = (p[11] << 8) | p[12]; it.near = p[13]; it.k_step = p[14]; it.effort = p[15];
+        return size_ok(it.h, it.w, max_px) && n_channel <= 1 && it.near <= kMaxNear && it.k_step >= kMinKStep && it.k_step <= kLevels &&
+               it.effort >= 1 && it.effort <= 3;
+    }
+    if (len >= 8 && p[0] == 'Q' && p[1] == '0' && p[2] == '.' && p[3] == '2') {
+        uint16_t q[4];
+        memcpy(q, p, 8);
+        it.kind = 1; it.h = q[2]; it.w = q[3]; it.near = it.effort = 0; it.k_step = kMinKStep;
+        return size_ok(it.h, it.w, max_px);
+    }
+    return 0;
+}
+
+static size_t decode_state_bytes(const DecodeItem &it) { return up256(it.kind ? kQDecodeStateBytes : kDecodeStateBytes); }
+
+// One launch round of a (codec, effort) class: every job advances by its `rows`.
+static bool decode_launch(const DecodeItem &first, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t st) {
+    return first.kind == 1 ? serial_qdecode_launch(d_jobs, h_jobs, n, st) : serial_decode_launch(d_jobs, h_jobs, n, st);
+}
+
+static bool ensure_decode_space(nblic_amd_ctx *c, size_t arena, int m) {
+    if (arena > c->dec_arena_cap) { hipFree(c->dec_arena); c->dec_arena = nullptr; c->dec_arena_cap = 0; HIP_OK(hipMalloc((void **)&c->dec_arena, arena)); c->dec_arena_cap = arena; }
+    if (m > c->dec_jobs_cap) {
+        hipFree(c->dec_jobs); c->dec_jobs = nullptr; c->dec_jobs_cap = 0;
+        HIP_OK(hipMalloc((void **)&c->dec_jobs, size_t(m) * sizeof(SerialJob)));
+        c->dec_jobs_cap = m;
+    }
+    return true;
+}
+
+// Parses and validates the headers, uploads the streams (their lengths are known here: running dry is an error),
+// works every (codec, effort) class present through its launches -- `rows` rows of every image per launch, the
+// state records carry the images from one launch to the next -- and copies the planes back.  status[k] = 0 / -1.
 static bool decode_batch(nblic_amd_ctx *c, int n, const unsigned char *const *streams, const size_t *lens,
                          unsigned char *const *imgs, const size_t *img_caps, int *hs, int *ws, int *nears, int *efforts, int *status) {
     if (hipSetDevice(c->device) != hipSuccess) return false;
-    constexpr size_t kQTab = 2 * 12 * 256 * sizeof(uint32_t) + size_t(12) * 32768;
-    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     std::vector<DecodeItem> items;
+    std::vector<std::vector<uint8_t>> qtabs;                            // per QNBLIC item, alive until the copies have been made
     size_t arena = 0;
     for (int k = 0; k < n; k++) {
         status[k] = -1; hs[k] = ws[k] = 0; nears[k] = efforts[k] = 0;
-        const unsigned char *p = streams[k];
-        DecodeItem it{k, 0, 0, 0, 0, 0, 0, lens[k]};
-        if (lens[k] >= kHeaderBytes + 4 && memcmp(p, "NBLIC0.3", 8) == 0) {
-            const int n_channel = p[8];
-            it.h = (p[9] << 8) | p[10]; it.w = (p[11] << 8) | p[12]; it.near = p[13]; it.k_step = p[14]; it.effort = p[15];
-            if (!size_ok(it.h, it.w, c->max_px) || n_channel > 1 || it.near > kMaxNear || it.k_step < kMinKStep || it.k_step > kLevels ||
-                it.effort < 1 || it.effort > 3) continue;
-        } else if (lens[k] >= 12 && p[0] == 'Q' && p[1] == '0' && p[2] == '.' && p[3] == '2') {
-            const uint16_t *q = reinterpret_cast<const uint16_t *>(p);
-            it.kind = 1; it.h = q[2]; it.w = q[3];
-            if (!size_ok(it.h, it.w, c->max_px)) continue;
-        } else continue;
+        DecodeItem it{k, 0, 0, 0, 0, 0, 0, lens[k], -1, -1};
+        if (!parse_stream_header(streams[k], lens[k], c->max_px, it)) continue;
+        if (it.kind == 0 && lens[k] < size_t(kHeaderBytes) + 4) continue;
         hs[k] = it.h; ws[k] = it.w; nears[k] = it.near; efforts[k] = it.effort;
         if (size_t(it.h) * size_t(it.w) > img_caps[k]) continue;
+        if (it.kind == 1) {                                              // QNBLIC: histogram tables parsed on the host; a stream whose tables
+            std::vector<uint8_t> tab(kQTab);                             // do not parse is refused here and never reaches the GPU
+            uint32_t *freq = reinterpret_cast<uint32_t *>(tab.data()), *start = freq + 12 * 256;
+            int hh = 0, ww = 0;
+            it.q_pos = q_decode_tables(reinterpret_cast<const uint16_t *>(streams[k]), lens[k] / 2, &hh, &ww, freq, start, tab.data() + 2 * 12 * 256 * sizeof(uint32_t));
+            if (it.q_pos < 0 || size_t(it.q_pos) * 2 + 4 > lens[k]) continue;
+            it.qtab = int(qtabs.size());
+            qtabs.push_back(std::move(tab));
+        }
         items.push_back(it);
-        arena += up(lens[k] + 2048) + up(size_t(it.h) * size_t(it.w)) + up(stats_doubles(it.effort, it.w) * sizeof(double)) + (it.kind ? up(kQTab) : 0);
+        arena += up256(lens[k] + 2048) + up256(size_t(it.h) * size_t(it.w)) + up256(stats_doubles(it.effort, it.w) * sizeof(double)) +
+                 decode_state_bytes(it) + (it.kind ? up256(kQTab) : 0);
     }
     if (items.empty()) return true;
     std::stable_sort(items.begin(), items.end(), [](const DecodeItem &a, const DecodeItem &b) { return a.kind * 4 + a.effort < b.kind * 4 + b.effort; });
     const int m = int(items.size());
-    if (arena > c->dec_arena_cap) { hipFree(c->dec_arena); c->dec_arena = nullptr; c->dec_arena_cap = 0; HIP_OK(hipMalloc((void **)&c->dec_arena, arena)); c->dec_arena_cap = arena; }
-    if (m > c->dec_jobs_cap) {
-        hipFree(c->dec_jobs); hipFree(c->dec_status); c->dec_jobs = nullptr; c->dec_status = nullptr; c->dec_jobs_cap = 0;
-        HIP_OK(hipMalloc((void **)&c->dec_jobs, size_t(m) * sizeof(SerialJob)));
-        HIP_OK(hipMalloc((void **)&c->dec_status, size_t(m) * sizeof(int)));
-        c->dec_jobs_cap = m;
-    }
+    if (!ensure_decode_space(c, arena, m)) return false;
     hipStream_t st = c->dec_stream;
     std::vector<SerialJob> jobs(static_cast<size_t>(m));
-    std::vector<uint8_t> qtab;
+    std::vector<SerialState> heads(static_cast<size_t>(m));
     size_t off = 0;
     for (int i = 0; i < m; i++) {
         const DecodeItem &it = items[size_t(i)];
         SerialJob &J = jobs[size_t(i)];
         J = SerialJob{};
-        uint8_t *d_stream = c->dec_arena + off; off += up(it.len + 2048);
-        J.recon = c->dec_arena + off; off += up(size_t(it.h) * size_t(it.w));
+        uint8_t *d_stream = c->dec_arena + off; off += up256(it.len + 2048);
+        J.recon = c->dec_arena + off; off += up256(size_t(it.h) * size_t(it.w));
         const size_t sb = stats_doubles(it.effort, it.w) * sizeof(double);
-        if (sb) { J.stats = reinterpret_cast<double *>(c->dec_arena + off); off += up(sb); HIP_OK(hipMemsetAsync(J.stats, 0, sb, st)); }
+        if (sb) { J.stats = reinterpret_cast<double *>(c->dec_arena + off); off += up256(sb); HIP_OK(hipMemsetAsync(J.stats, 0, sb, st)); }
+        J.state = reinterpret_cast<SerialState *>(c->dec_arena + off); off += decode_state_bytes(it);
         HIP_OK(hipMemsetAsync(d_stream + (it.len & ~size_t(3)), 0, 2048, st));                 // the window reads whole 512-byte blocks past the end
         HIP_OK(hipMemcpyAsync(d_stream, streams[it.k], it.len, hipMemcpyHostToDevice, st));
-        J.stream = d_stream; J.stream_len = it.len; J.status = c->dec_status + i;
+        J.stream = d_stream;
         J.h = it.h; J.w = it.w; J.near = it.near; J.k_step = it.k_step; J.effort = it.effort;
-        if (it.kind == 1) {                                              // QNBLIC: histogram tables parsed on the host
-            qtab.resize(kQTab);
-            uint32_t *freq = reinterpret_cast<uint32_t *>(qtab.data()), *start = freq + 12 * 256;
-            uint8_t *slot = qtab.data() + 2 * 12 * 256 * sizeof(uint32_t);
-            int hh = 0, ww = 0;
-            const long pos = q_decode_tables(reinterpret_cast<const uint16_t *>(streams[it.k]), it.len / 2, &hh, &ww, freq, start, slot);
-            uint8_t *d_tab = c->dec_arena + off; off += up(kQTab);
-            J.q_pos = pos < 0 ? it.len : size_t(pos); J.q_words = pos < 0 ? 0 : it.len / 2;            // a bad table makes the kernel report failure
-            HIP_OK(hipMemcpy(d_tab, qtab.data(), kQTab, hipMemcpyHostToDevice));                     // synchronous: qtab is reused by the next image
+        J.rows = serial_rows_per_launch(it.h, it.w, it.kind ? 1 : it.effort, c->serial_rows);
+        SerialState &H = heads[size_t(i)];
+        H = SerialState{};
+        H.pos = it.kind ? (unsigned long long)(it.q_pos) * 2ull : (unsigned long long)(kHeaderBytes);
+        H.avail = it.len; H.final_ = 1;
+        HIP_OK(hipMemcpyAsync(J.state, &H, sizeof H, hipMemcpyHostToDevice, st));
+        if (it.kind == 1) {
+            uint8_t *d_tab = c->dec_arena + off; off += up256(kQTab);
+            HIP_OK(hipMemcpyAsync(d_tab, qtabs[size_t(it.qtab)].data(), kQTab, hipMemcpyHostToDevice, st));
             J.q_freq = reinterpret_cast<const uint32_t *>(d_tab); J.q_start = J.q_freq + 12 * 256; J.q_slot = d_tab + 2 * 12 * 256 * sizeof(uint32_t);
         }
     }
     HIP_OK(hipMemcpyAsync(c->dec_jobs, jobs.data(), size_t(m) * sizeof(SerialJob), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemsetAsync(c->dec_status, 0xFF, size_t(m) * sizeof(int), st));
     for (int i0 = 0; i0 < m;) {
         int i1 = i0 + 1;
         while (i1 < m && items[size_t(i1)].kind == items[size_t(i0)].kind && items[size_t(i1)].effort == items[size_t(i0)].effort) i1++;
-        const bool ok = items[size_t(i0)].kind == 1 ? serial_qdecode_launch(c->dec_jobs + i0, jobs.data() + i0, i1 - i0, st)
-                                                    : serial_decode_launch(c->dec_jobs + i0, jobs.data() + i0, i1 - i0, st);
-        if (!ok) { fprintf(stderr, "[nblic_amd] decode launch failed\n"); hipStreamSynchronize(st); return false; }
+        int launches = 1;
+        for (int i = i0; i < i1; i++) launches = std::max(launches, serial_launches(jobs[size_t(i)].h, jobs[size_t(i)].rows));
+        for (int l = 0; l < launches; l++)
+            if (!decode_launch(items[size_t(i0)], c->dec_jobs + i0, jobs.data() + i0, i1 - i0, st)) { fprintf(stderr, "[nblic_amd] decode launch failed\n"); hipStreamSynchronize(st); return false; }
+        c->serial_launch_count += launches;
         i0 = i1;
     }
-    std::vector<int> st_host(static_cast<size_t>(m), -1);
-    HIP_OK(hipMemcpyAsync(st_host.data(), c->dec_status, size_t(m) * sizeof(int), hipMemcpyDeviceToHost, st));
     for (int i = 0; i < m; i++) {
         const DecodeItem &it = items[size_t(i)];
+        HIP_OK(hipMemcpyAsync(&heads[size_t(i)], jobs[size_t(i)].state, sizeof(SerialState), hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(imgs[it.k], jobs[size_t(i)].recon, size_t(it.h) * size_t(it.w), hipMemcpyDeviceToHost, st));
     }
     HIP_OK(hipStreamSynchronize(st));
-    for (int i = 0; i < m; i++) status[items[size_t(i)].k] = st_host[size_t(i)] == 0 ? 0 : -1;
+    for (int i = 0; i < m; i++) status[items[size_t(i)].k] = heads[size_t(i)].status == kDone ? 0 : -1;
     return true;
 }
 
-// How many bytes of the caller's stream may be read.  The reference's decoders take no length (NBLIC.h:72,
-// QNBLIC.h:16): they simply read what the encoder wrote.  The drop-in shims bound their copy by the end of
-// the readable mapping that holds `p` and by the worst case a stream of this geometry can have.
-static size_t readable_span(const unsigned char *p, size_t want) {
-    FILE *f = fopen("/proc/self/maps", "r");
-    if (!f) return want;
-    unsigned long lo, hi, addr = (unsigned long)p, end = 0;
-    char perms[8], line[512];
-    while (fgets(line, sizeof line, f)) {
-        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perms) != 3 || perms[0] != 'r') { if (end) break; continue; }
-        if (!end) { if (addr >= lo && addr < hi) end = hi; }
-        else if (lo == end) end = hi;                                   // contiguous readable mapping
-        else break;
+// ---- the drop-in decoders: a stream whose length nobody tells us ------------------------------------
+// The reference's decoders take no length (NBLIC.h:72, QNBLIC.h:16): they read what the encoder wrote, byte by byte.
+// The shims fetch the stream in steps of `feed_chunk` bytes ON DEMAND -- the decoder stops in front of a row when it is
+// about to run short (SerialState kStarved), the next step is copied in, it goes on -- so that no byte beyond what the
+// decoder consumes plus one step is read from the caller's buffer.  Every step is copied by the KERNEL (write(2) into a
+// pipe, read back): where the caller's memory ends (the next page unmapped or protected, a file mapping past its end)
+// the copy comes back short instead of raising a signal, and a stream that sits right at the end of a mapping is read
+// exactly to its last byte.
+static size_t safe_copy(nblic_amd_ctx *c, void *dst, const void *src, size_t n) {
+    if (c->feed_pipe[0] < 0 && pipe(c->feed_pipe) != 0) { c->feed_pipe[0] = c->feed_pipe[1] = -1; return 0; }
+    size_t done = 0;
+    while (done < n) {
+        const size_t want = n - done < 65536 ? n - done : 65536;                    // a fresh pipe holds 64 KB: the write never blocks
+        const ssize_t k = write(c->feed_pipe[1], static_cast<const char *>(src) + done, want);
+        if (k <= 0) break;                                                          // EFAULT: not one more byte can be read
+        size_t got = 0;
+        while (got < size_t(k)) {
+            const ssize_t r = read(c->feed_pipe[0], static_cast<char *>(dst) + done + got, size_t(k) - got);
+            if (r <= 0) return done + got;
+            got += size_t(r);
+        }
+        done += size_t(k);
+        if (size_t(k) < want) break;                                                // stopped at the end of the readable memory
     }
-    fclose(f);
-    if (!end) return want;
-    const size_t avail = size_t(end - addr);
-    return avail < want ? avail : want;
+    return done;
+}
+
+// Decodes ONE stream that starts at p; *ph .. *peffort receive the header fields.  0 / -1.
+static int decode_fed(nblic_amd_ctx *c, const unsigned char *p, bool qnblic, unsigned char *img, int *ph, int *pw, int *pnear, int *peffort) {
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    c->fed_bytes = 0;
+    unsigned char head[kHeaderBytes];
+    const size_t head_want = qnblic ? 8 : size_t(kHeaderBytes);
+    if (safe_copy(c, head, p, head_want) < head_want) return -1;
+    DecodeItem it{0, 0, 0, 0, 0, 0, 0, head_want, -1, -1};
+    if (!parse_stream_header(head, head_want, c->max_px, it) || (it.kind == 1) != qnblic) return -1;
+    *ph = it.h; *pw = it.w;
+    if (pnear) *pnear = it.near;
+    if (peffort) *peffort = it.effort;
+    const size_t npx = size_t(it.h) * size_t(it.w);
+    // no valid stream of this geometry is longer (worst case seen: 1.0025 B/px + 20; QNBLIC: a word per pixel + tables)
+    const size_t bound = qnblic ? 2 * npx + 32768 + 16 : npx + npx / 8 + 4096;
+    const size_t sb = stats_doubles(it.effort, it.w) * sizeof(double);
+    const size_t arena = up256(bound + 2048) + up256(npx) + up256(sb) + decode_state_bytes(it) + (qnblic ? up256(kQTab) : 0);
+    if (!ensure_decode_space(c, arena, 1)) return -1;
+    hipStream_t st = c->dec_stream;
+    size_t off = 0;
+    uint8_t *d_stream = c->dec_arena + off; off += up256(bound + 2048);
+    SerialJob J{};
+    J.recon = c->dec_arena + off; off += up256(npx);
+    if (sb) { J.stats = reinterpret_cast<double *>(c->dec_arena + off); off += up256(sb); }
+    J.state = reinterpret_cast<SerialState *>(c->dec_arena + off); off += decode_state_bytes(it);
+    uint8_t *d_tab = qnblic ? c->dec_arena + off : nullptr;
+    J.stream = d_stream;
+    J.h = it.h; J.w = it.w; J.near = it.near; J.k_step = it.k_step; J.effort = it.effort;
+    J.rows = serial_rows_per_launch(it.h, it.w, qnblic ? 1 : it.effort, c->serial_rows);
+    if (qnblic) { J.q_freq = reinterpret_cast<const uint32_t *>(d_tab); J.q_start = J.q_freq + 12 * 256; J.q_slot = d_tab + 2 * 12 * 256 * sizeof(uint32_t); }
+    if (hipMemcpyAsync(c->dec_jobs, &J, sizeof J, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+
+    std::vector<uint8_t> host;                                           // the stream as far as it has been fetched
+    bool final_ = false;
+    auto feed = [&](size_t want_total) -> bool {                         // extends `host` (and the device copy) to want_total bytes, or to where the memory ends
+        if (want_total > bound) want_total = bound;
+        const size_t have = host.size();
+        if (want_total <= have) { if (have >= bound) final_ = true; return true; }
+        host.resize(want_total);
+        const size_t got = safe_copy(c, host.data() + have, p + have, want_total - have);
+        host.resize(have + got);
+        if (got < want_total - have || host.size() >= bound) final_ = true;
+        c->fed_bytes = long(host.size());
+        if (got == 0) return true;
+        // (the kernel fetches whole 512-byte blocks beyond what is there; it never CONSUMES a byte at or beyond `avail`)
+        return hipMemcpyAsync(d_stream + have, host.data() + have, got, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    };
+    const size_t chunk = c->feed_chunk < 4096 ? 4096 : c->feed_chunk;
+    if (!feed(chunk)) return -1;
+    SerialState H{};
+    if (qnblic) {                                                        // the histogram tables sit in front of the rANS words: at most 12 x 256 codes
+        std::vector<uint8_t> tab(kQTab);
+        uint32_t *freq = reinterpret_cast<uint32_t *>(tab.data()), *start = freq + 12 * 256;
+        int hh = 0, ww = 0;
+        long pos = q_decode_tables(reinterpret_cast<const uint16_t *>(host.data()), host.size() / 2, &hh, &ww, freq, start, tab.data() + 2 * 12 * 256 * sizeof(uint32_t));
+        if (pos < 0 && !final_ && host.size() < 65536) {                 // the tables may simply not be in hand yet
+            if (!feed(65536)) return -1;
+            pos = q_decode_tables(reinterpret_cast<const uint16_t *>(host.data()), host.size() / 2, &hh, &ww, freq, start, tab.data() + 2 * 12 * 256 * sizeof(uint32_t));
+        }
+        if (pos < 0) return -1;
+        if (hipMemcpyAsync(d_tab, tab.data(), kQTab, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        H.pos = (unsigned long long)(pos) * 2ull;
+    } else {
+        H.pos = kHeaderBytes;
+    }
+    const int launches = serial_launches(it.h, J.rows);
+    for (int attempt = 0; attempt < 2; attempt++) {                      // the second attempt (whole stream in hand) only after kStarvedMidRow
+        if (sb && hipMemsetAsync(J.stats, 0, sb, st) != hipSuccess) return -1;
+        SerialState S = H;
+        for (;;) {
+            S.avail = host.size(); S.final_ = final_ ? 1 : 0; S.status = kRunning;
+            // header fields the host owns are rewritten; on a resumed image the kernel's own fields come back unchanged
+            if (hipMemcpyAsync(J.state, &S, sizeof S, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+            for (int l = 0; l < launches; l++)                           // launches after a stop return at once
+                if (!decode_launch(it, c->dec_jobs, &J, 1, st)) return -1;
+            c->serial_launch_count += launches;
+            if (hipMemcpyAsync(&S, J.state, sizeof S, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+            if (S.status == kStarved && !final_) { if (!feed(host.size() + chunk)) return -1; continue; }
+            break;
+        }
+        if (S.status == kDone) {
+            if (hipMemcpyAsync(img, J.recon, npx, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+            return 0;
+        }
+        if (S.status != kStarvedMidRow || final_) return -1;
+        if (!feed(bound)) return -1;                                      // a row dearer than the margin allows: everything there is, from the top
+        final_ = true;
+    }
+    return -1;
 }
 
 // ---- default context behind the drop-in entry points ---------------------------------------
@@ -1473,7 +1623,8 @@ void nblic_amd_destroy(nblic_amd_ctx *c) {
     for (auto &g : c->groups) group_free(g);
     for (auto &cb : c->cbufs) if (cb.p) hipFree(cb.p);
     for (auto &cs : c->copy_streams) if (cs) hipStreamDestroy(cs);
-    hipFree(c->dec_arena); hipFree(c->dec_jobs); hipFree(c->dec_status);
+    hipFree(c->dec_arena); hipFree(c->dec_jobs);
+    if (c->feed_pipe[0] >= 0) { close(c->feed_pipe[0]); close(c->feed_pipe[1]); }
     if (c->dec_stream) hipStreamDestroy(c->dec_stream);
     delete c;
 }
@@ -1481,6 +1632,24 @@ void nblic_amd_destroy(nblic_amd_ctx *c) {
 void nblic_amd_set_max_pixels(nblic_amd_ctx *c, long max_pixels) {
     if (!c) c = default_ctx();                                               // NULL: the context behind the drop-in entry points
     if (c) c->max_px = max_pixels > 0 ? max_pixels : kMaxPixels;
+}
+void nblic_amd_set_serial_rows(nblic_amd_ctx *c, int rows) {
+    if (!c) c = default_ctx();
+    if (c) { std::lock_guard<std::mutex> g(c->api); c->serial_rows = rows > 0 ? rows : 0; }
+}
+long nblic_amd_serial_launches(nblic_amd_ctx *c) {
+    if (!c) c = default_ctx();
+    if (!c) return -1;
+    std::lock_guard<std::mutex> l(c->stat_m);
+    return c->serial_launch_count;
+}
+void nblic_amd_set_feed_chunk(nblic_amd_ctx *c, size_t bytes) {
+    if (!c) c = default_ctx();
+    if (c) { std::lock_guard<std::mutex> g(c->api); c->feed_chunk = bytes ? bytes : (size_t(1) << 20); }
+}
+long nblic_amd_last_fed_bytes(nblic_amd_ctx *c) {
+    if (!c) c = default_ctx();
+    return c ? c->fed_bytes : -1;
 }
 void nblic_amd_enable_timing(nblic_amd_ctx *c, int on) { c->timing = on != 0; c->timing_mask = on == 2 ? kRooflineStages : ~0ull; }
 
@@ -1515,7 +1684,7 @@ nblic_amd_batch *nblic_amd_encode_batch_begin(nblic_amd_ctx *c, int n_images, co
 
 int nblic_amd_encode_batch_end(nblic_amd_ctx *c, nblic_amd_batch *b) {
     if (!c || !b) return -1;
-    const bool ok = encode_wait(c, b) && !c->failed;
+    const bool ok = encode_wait(c, b) && !c->broken;         // b->ok and b->lens: this batch's images only
     report_coders(c);
     delete b;
     return ok ? 0 : -1;
@@ -1561,7 +1730,7 @@ int nblic_amd_encode_batch_modes(nblic_amd_ctx *c, int n_images, const unsigned 
     nblic_amd_batch b;
     queue_batch(c, nblic_amd_ctx::SubmitItem{&b, n_images, imgs, imgs_on_device != 0, heights, widths, outs, out_caps, out_lens, nears, efforts, recons});
     const bool ok = encode_wait(c, &b);
-    return ok && !c->failed ? 0 : -1;
+    return ok && !c->broken ? 0 : -1;
 }
 
 int nblic_amd_decode_batch(nblic_amd_ctx *c, int n_images, const unsigned char *const *streams, const size_t *stream_lens,
@@ -1614,15 +1783,10 @@ int NBLICcompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int h
 
 int NBLICdecompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int *p_height, int *p_width, int *p_near, int *p_effort) {
     (void)verbose;
-    if (memcmp(p_buf, "NBLIC0.3", 8) != 0) return -1;                        // NBLIC.c:698-712
-    const size_t n = (size_t(p_buf[9]) << 8 | p_buf[10]) * (size_t(p_buf[11]) << 8 | p_buf[12]);
     nblic_amd_ctx *c = default_ctx();
     if (!c) return -1;
-    const unsigned char *streams[1] = {p_buf};
-    unsigned char *imgs[1] = {p_img};
-    size_t lens[1] = {readable_span(p_buf, n + n / 8 + 4096)}, caps[1] = {SIZE_MAX};      // worst case seen: 1.0025 B/px + 20
-    int status[1] = {-1};
-    return nblic_amd_decode_batch(c, 1, streams, lens, imgs, caps, p_height, p_width, p_near, p_effort, status);
+    std::lock_guard<std::mutex> g(c->api);
+    return decode_fed(c, p_buf, false, p_img, p_height, p_width, p_near, p_effort);          // NBLIC.c:698-712, :924-926
 }
 
 int nblic_amd_qencode_batch(nblic_amd_ctx *c, int n_images, const unsigned char *const *imgs, int imgs_on_device,
@@ -1647,14 +1811,8 @@ int QNBLICcompress(uint16_t *p_buf, unsigned char *p_img, int height, int width)
 int QNBLICdecompress(uint16_t *p_buf, unsigned char *p_img, int *p_height, int *p_width) {
     nblic_amd_ctx *c = default_ctx();
     if (!c) return -1;
-    const unsigned char *pb = reinterpret_cast<const unsigned char *>(p_buf);
-    if (readable_span(pb, 8) < 8 || memcmp(pb, "Q0.2", 4) != 0) return -1;    // QNBLIC.c:475-486
-    const size_t n = size_t(p_buf[2]) * size_t(p_buf[3]);
-    const unsigned char *streams[1] = {pb};
-    unsigned char *imgs[1] = {p_img};
-    size_t lens[1] = {readable_span(pb, 2 * n + 32768) & ~size_t(1)}, caps[1] = {SIZE_MAX};
-    int status[1] = {-1}, near = 0, effort = 0;
-    return nblic_amd_decode_batch(c, 1, streams, lens, imgs, caps, p_height, p_width, &near, &effort, status);
+    std::lock_guard<std::mutex> g(c->api);
+    return decode_fed(c, reinterpret_cast<const unsigned char *>(p_buf), true, p_img, p_height, p_width, nullptr, nullptr);   // QNBLIC.c:475-555
 }
 int QNBLICcompressMultiThread(uint16_t *p_buf, unsigned char *p_img, int height, int width) {
     return QNBLICcompress(p_buf, p_img, height, width);                      // QNBLIC.c:872-883: same stream either way

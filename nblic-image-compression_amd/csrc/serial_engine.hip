@@ -16,6 +16,7 @@
 //     in HBM, the next pixel's columns prefetched a pixel ahead) and handed to the row layout
 //     through 1 KB of LDS.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,8 +46,8 @@ __device__ __forceinline__ NB_GLOBAL T *gp(T *p) { return (NB_GLOBAL T *)p; }
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);               // every lane is written: no `old` value to carry (it would cost a copy per word)
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 constexpr int kRor1 = 0x121, kRor2 = 0x122, kRor4 = 0x124, kRor8 = 0x128;   // rotate right inside each 16-lane row
@@ -64,6 +65,16 @@ __device__ __forceinline__ double row_max(double v) {
 __device__ __forceinline__ double row_sum(double v) {
     v += dpp_f64<kRor1>(v); v += dpp_f64<kRor2>(v); v += dpp_f64<kRor4>(v); v += dpp_f64<kRor8>(v);
     return v;
+}
+// The value a lane of half HALF (0: lanes 0..31, 1: lanes 32..63) holds, in both halves of the wave, lane for lane:
+// v_permlane32_swap_b32 swaps lanes 32..63 of its first operand with lanes 0..31 of its second, so with the same value
+// in both operands the first result is the lower half's value everywhere and the second the upper half's (gfx950).
+template <int HALF>
+__device__ __forceinline__ double bcast_half(double v) {
+    const unsigned lo = unsigned(__double2loint(v)), hi = unsigned(__double2hiint(v));
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(int(b[HALF]), int(a[HALF]));
 }
 // value of lane (byte_addr / 4)
 __device__ __forceinline__ double fetch_f64(double v, int byte_addr) {
@@ -97,14 +108,17 @@ struct ModelLds {
     LsqLds q;
 };
 struct DecodeLds {
+    // what a resumed launch reloads, in the order of the state record (serial_engine.h kDecodeStateBytes)
     int ctx[kContexts];
-    uint16_t qlut[208];
     uint32_t cnt[kLevels][kTreeNodes];       // c0 | c1 << 16 (both <= 8224)
     int count[512][kMapSyms];
     uint8_t rank_of[512][kMapSyms], sym_at[512][kMapSyms];
+    // rebuilt by every launch
+    uint16_t qlut[208];
     uint32_t sbuf[256];                      // 1 KB window of the stream, two halves
     LsqLds q;
 };
+static_assert(offsetof(DecodeLds, qlut) == kDecodeStateBytes - sizeof(SerialState), "state record = the leading tables");
 
 // activity -> (qu, qv, qw) (model.h quantise) as a table: the interpolation divides by a level gap
 __device__ void fill_qlut(uint16_t *qlut) {
@@ -171,53 +185,75 @@ __device__ __noinline__ int lsq_solve_int(LsqLds &S, int n, i64 bias, i64 *px_q1
     return 1;
 }
 
-// ---- least squares in registers: the pixel's two systems side by side ---------------------------
-// Lane layout: row = lane & 15 of system (lane >> 4) & 1 (the upper half of the wave mirrors the lower).
-// M[0..N) = the row of A, M[N] = its right-hand side.  Returns the Q12 prediction of the lane's system
-// in every lane of its 16-lane row; `ok` false = a pivot was zero (NBLIC.c:118).
+// ---- least squares in registers: the pixel's two systems side by side, columns split over the half-waves ----
+// Lane layout: row = lane & 15 of system (lane >> 4) & 1; half = lane >> 5 owns the columns of its parity: slot s of
+// M holds column 2 s + half of the augmented row [A | b] (column N = the right-hand side, in half 0; half 1's last
+// slot is unused and stays 0).  So the four 16-lane rows of the wave are (system 0, even columns), (system 1, even),
+// (system 0, odd), (system 1, odd), and an elimination step costs ceil((N - k) / 2) multiply-divides instead of N - k.
+// Per step the pivot column is handed to the other half with v_permlane32_swap (no LDS), every 16-lane row then finds
+// the pivot for itself (DPP) and fetches the pivot row's entries of ITS columns (ds_bpermute inside the row).
+// Rows never move: each carries its position.  The broadcast columns are kept: once a row has been placed its
+// entries no longer change, so column k as seen at step k is what the back substitution needs above the diagonal.
+// Returns the Q12 prediction of the lane's system in every lane of its 16-lane row; ok = 0: a pivot was zero (NBLIC.c:118).
 template <int N>
-__device__ __forceinline__ double lsq_solve_rows(double (&M)[N + 1], const int row, const int row_base4, const int8_t *vn8,
-                                                 lsq::Guard &g, int &ok) {
+__device__ __forceinline__ double lsq_solve_split(double (&M)[(N + 2) / 2], const int row, const int half, const int row_base4,
+                                                  const int8_t *vn8, lsq::Guard &g, int &ok) {
+    constexpr int kS = (N + 2) / 2;
+    static_assert((N & 1) == 0, "the right-hand side has to fall to half 0");
     // (flags are ints in vector registers: as booleans they would each pin a scalar register pair for the whole solve)
     const int live = row < N;
     int pos = row, at_sum = 0;
     int at[N];
+    double col[N];
     double diag = 1.0;
     ok = 1;
 #pragma unroll
     for (int k = 0; k + 1 < N; k++) {
+        const double ck = (k & 1) ? bcast_half<1>(M[k >> 1]) : bcast_half<0>(M[k >> 1]);
+        col[k] = ck;
+        // every lane prepares the reciprocal of ITS candidate while the pivot search runs: the winner's is fetched with
+        // its value, and the reciprocal's dependent chain is off the step's critical path
+        const double rs_c = lsq::recip_short(ck);
         // pivot: largest |entry| of column k among the rows at positions >= k, first position wins (NBLIC.c:121-127)
-        const double key = row_max((live & (pos >= k)) ? fma(fabs(M[k]), 256.0, double((15 - pos) * 16 + row)) : -1.0);
+        const double key = row_max((live & (pos >= k)) ? fma(fabs(ck), 256.0, double((15 - pos) * 16 + row)) : -1.0);
         const int tag = int(fma(-256.0, floor(key * (1.0 / 256.0)), key));
         const int c = tag & 15, pc = 15 - (tag >> 4);
+        const int src = row_base4 | (c << 2);
+        const int s0 = (k + 1) >> 1;                                     // first slot with a column beyond k in either half
+        const double d = fetch_f64(ck, src), rs = fetch_f64(rs_c, src);
+        double prow[kS];                                                 // the pivot row's entries of this lane's columns: all requests go out together
+#pragma unroll
+        for (int s = s0; s < kS; s++) prow[s] = fetch_f64(M[s], src);
         at[k] = c; at_sum += c;
         pos = pos == k ? pc : pos;                                       // the row that sat at k takes the pivot's place
         pos = (live & (row == c)) ? k : pos;
-        const int src = row_base4 | (c << 2);
-        const double d = fetch_f64(M[k], src);
         diag = pos == k ? d : diag;
         ok &= int(d != 0.0);
-        const double rs = lsq::recip_short(d);
-        const double l = (live & (pos > k)) ? M[k] : 0.0;                // rows already placed take no part: their quotient is 0
+        const double l = (live & (pos > k)) ? ck : 0.0;                  // rows already placed take no part: their quotient is 0
 #pragma unroll
-        for (int j = k + 1; j <= N; j++) {
-            M[j] -= lsq::muldiv_trunc(fetch_f64(M[j], src), l, d, rs, g);
-            g.see_entry(M[j]);
+        for (int s = s0; s < kS; s++) {
+            // for even k half 0's slot s0 is the pivot column itself: it is done with (the reference never reads it again)
+            const double ls = (!(k & 1) && s == s0) ? (half ? l : 0.0) : l;
+            M[s] -= lsq::muldiv_trunc(prow[s], ls, d, rs, g);
+            g.see_entry(M[s]);
         }
     }
     at[N - 1] = N * (N - 1) / 2 - at_sum;
-    diag = (live & (pos == N - 1)) ? M[N - 1] : diag;
+    col[N - 1] = bcast_half<1>(M[(N - 1) >> 1]);
+    diag = (live & (pos == N - 1)) ? col[N - 1] : diag;
+    double rhs = bcast_half<0>(M[N >> 1]);                               // both halves finish the solve alike
+    const double rs_own = lsq::recip_short(diag);                        // every row's own reciprocal at once, fetched below
 #pragma unroll
     for (int k = N - 1; k > 0; k--) {                                     // back substitution on the right-hand side (NBLIC.c:148-158)
         const int src = row_base4 | (at[k] << 2);
-        const double d = fetch_f64(diag, src), bk = fetch_f64(M[N], src);
+        const double d = fetch_f64(diag, src), rsd = fetch_f64(rs_own, src), bk = fetch_f64(rhs, src);
         ok &= int(d != 0.0);
-        const double l = (live & (pos < k)) ? M[k] : 0.0;
-        M[N] -= lsq::muldiv_trunc(bk, l, d, lsq::recip_short(d), g);
-        g.see_entry(M[N]);
+        const double l = (live & (pos < k)) ? col[k] : 0.0;
+        rhs -= lsq::muldiv_trunc(bk, l, d, rsd, g);
+        g.see_entry(rhs);
     }
     const int v = vn8[live ? pos : 14];
-    const double t = lsq::term(live ? M[N] : 0.0, v, diag, g);            // NBLIC.c:233-236
+    const double t = lsq::term(live ? rhs : 0.0, v, diag, rs_own, g);     // NBLIC.c:233-236
     return double(kMid << lsq::kFb1) + row_sum(live ? t : 0.0);
 }
 
@@ -271,18 +307,23 @@ __device__ void lsq_row_prepare(const LsqEntries<N> &en, NB_GLOBAL double *F, NB
 template <int N>
 struct LsqWalk {
     using T = LsqEntries<N>;
+    static constexpr int kS = (N + 2) / 2;                               // column slots per lane (lsq_solve_split)
     LsqEntries<N> en;
     double E[T::kSlots], Bj[T::kSlots], Fj[T::kSlots], Bn[T::kSlots], Fn[T::kSlots];
     NB_GLOBAL double *Bst, *Fst;
-    int bias, b1, b2, lane, row, row_base4, w;
-    i64 p1, p2;
+    int bias, b1, b2, lane, row, half, row_base4, w;
+    int d_base, d_rhs, diag_slot;                                        // where the lane's slots sit in S.D; which slot (if any) is on the diagonal
+    int p1, p2;                                                          // Q12 predictions (<= 255 << 12)
     bool ok1, ok2;
 
-    __device__ void init(double *stats, int w_, int lane_) {
-        lane = lane_; w = w_; row = lane & 15; row_base4 = (lane & 48) << 2;
+    __device__ void init(double *stats, int w_, int lane_, int bias_) {
+        lane = lane_; w = w_; row = lane & 15; half = lane >> 5; row_base4 = (lane & 48) << 2;
         Bst = gp(stats); Fst = gp(stats) + size_t(w) * T::kStride;
-        bias = lsq::kBiasInit;
+        bias = bias_;
         en.init(lane);
+        const int r = row < N ? row : N - 1;                             // the idle lanes of a row mirror its last system row (they never take part)
+        d_base = 1 + N + r * N + half; d_rhs = 1 + r;
+        diag_slot = (row < N && ((row - half) & 1) == 0 && row >= half) ? (row - half) >> 1 : -1;
     }
     __device__ __forceinline__ void load_cols(int j, double (&b)[T::kSlots], double (&f)[T::kSlots]) const {
         const int jj = j < w ? j : w - 1;                                 // the prefetch past the row end re-reads the last column
@@ -306,39 +347,35 @@ struct LsqWalk {
         load_cols(j + 1, Bn, Fn);                                         // next pixel's columns: a whole pixel ahead of their use
         lsq::bias_pair(bias, b1, b2);
         const int bs = (lane & 16) ? b2 : b1;
-        const int r = row < N ? row : N - 1;
-        double M[N + 1];
+        const double reg = double(bs * N);
+        double M[kS];
 #pragma unroll
-        for (int c = 0; c < N; c++) M[c] = S.D[1 + N + r * N + c];
-        M[N] = S.D[1 + r] + double(bs << lsq::kFb3);
-#pragma unroll
-        for (int c = 0; c < N; c++) M[c] = (row == c) ? M[c] + double(bs * N) : M[c];
-        if (row >= N) {
-#pragma unroll
-            for (int c = 0; c <= N; c++) M[c] = 0.0;
+        for (int s = 0; s + 1 < kS; s++) {                                // slots 0 .. kS-2 are matrix columns in both halves
+            M[s] = S.D[d_base + 2 * s];
+            M[s] = diag_slot == s ? M[s] + reg : M[s];
         }
+        M[kS - 1] = half ? 0.0 : S.D[d_rhs] + double(bs << lsq::kFb3);   // the right-hand side (half 0) / nothing (half 1)
         lsq::Guard g;
         int ok;
-        const double p = lsq_solve_rows<N>(M, row, row_base4, S.vn8, g, ok);
+        const double p = lsq_solve_split<N>(M, row, half, row_base4, S.vn8, g, ok);
         const double pc = p < 0.0 ? 0.0 : (p > double(kMaxVal << lsq::kFb1) ? double(kMaxVal << lsq::kFb1) : p);
         const int pi = int(pc);
         const u64 bad = __ballot(!g.ok());
         p1 = __builtin_amdgcn_readlane(pi, 0); p2 = __builtin_amdgcn_readlane(pi, 16);
         const u64 okm = __ballot(ok != 0);
         ok1 = (okm & 1ull) != 0; ok2 = ((okm >> 16) & 1ull) != 0;
-        if (bad & 0xFFFFFFFFull) {                                       // magnitudes left the exact range: integers decide (rare)
+        if (bad) {                                                       // magnitudes left the exact range: integers decide (rare)
             i64 q1 = 0, q2 = 0;
             ok1 = lsq_solve_int(S, N, b1, &q1) != 0;
             ok2 = lsq_solve_int(S, N, b2, &q2) != 0;
             const i64 top = i64(kMaxVal) << lsq::kFb1;
-            p1 = q1 < 0 ? 0 : (q1 > top ? top : q1); p2 = q2 < 0 ? 0 : (q2 > top ? top : q2);
+            p1 = int(q1 < 0 ? 0 : (q1 > top ? top : q1)); p2 = int(q2 < 0 ? 0 : (q2 > top ? top : q2));
         }
     }
     // fold the coded pixel in (NBLIC.c:242-283, :882-893) and publish the next pixel's statistics; S.vn8[15] = x' - 128 is set
-    __device__ __forceinline__ void update(LsqLds &S, int j, int xr, i64 p1_used) {
-        const i64 xq = i64(xr) << lsq::kFb1;
-        const i64 e1 = abs64(p1_used - xq);
-        const double s_curr = double(e1);
+    __device__ __forceinline__ void update(LsqLds &S, int j, int xr, int p1_used) {
+        const int xq = xr << lsq::kFb1;
+        const double s_curr = double(iabs(p1_used - xq));
         const double e0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(E[0]), 0), __builtin_amdgcn_readlane(__double2loint(E[0]), 0));
         const double f0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Fj[0]), 0), __builtin_amdgcn_readlane(__double2loint(Fj[0]), 0));
         const double s_sum = (e0 + f0) + floor(s_curr * 1.5);
@@ -352,7 +389,7 @@ struct LsqWalk {
             if (en.active[s]) Bst[size_t(j) * T::kStride + size_t(lane + 64 * s)] = b;
             E[s] = en.decay(E[s], s) + b;
         }
-        if (ok1 && ok2) bias = (abs64(p1 - xq) > abs64(p2 - xq)) ? b2 : b1;
+        if (ok1 && ok2) bias = (iabs(p1 - xq) > iabs(p2 - xq)) ? b2 : b1;
 #pragma unroll
         for (int s = 0; s < T::kSlots; s++) {
             if (en.active[s]) S.D[lane + 64 * s] = E[s] + Fn[s];
@@ -361,7 +398,8 @@ struct LsqWalk {
     }
 };
 
-// pack the ten regressors (a,b,c,d,e,f,t,h,q,g, NBLIC.c:164-183) as bytes and store them with one LDS write per word
+// pack the ten regressors (a,b,c,d,e,f,t,h,q,g, NBLIC.c:164-183) as bytes; every lane stores the same three words
+// (one LDS write each, no divergence)
 __device__ __forceinline__ void store_regressors(int8_t *vn8, const Taps &t) {
     auto b = [](int v) { return uint32_t(v - kMid) & 0xFFu; };
     uint32_t *w = reinterpret_cast<uint32_t *>(vn8);
@@ -419,18 +457,27 @@ struct TapWindow {
 // taps are twelve LDS reads issued together; otherwise (rows wider than the LDS left over) they come
 // from the reconstruction in memory.  The two variants are separate code: one generic accessor would
 // turn every tap into a flat load with a branch and a full wait of its own.
+// A launch works on rows [i0, i1) of the image (serial_engine.h: resumable launches).
 template <int N, bool CACHED>
-__device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const SerialJob &J, const int rs) {
-    const int w = J.w, h = J.h, lane = int(threadIdx.x);
+__device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const SerialJob &J, const int rs, const int i0, const int i1, int &bias_io) {
+    const int w = J.w, lane = int(threadIdx.x);
     const NearParams np = near_params(J.near);
     const auto img = gp(J.img);
     const auto recon = gp(J.recon);
     const auto rec1 = gp(J.rec1);
     const auto pxs = gp(J.pxs);
     LsqWalk<N> lw;
-    if constexpr (N > 0) lw.init(J.stats, w, lane);
+    if constexpr (N > 0) lw.init(J.stats, w, lane, bias_io);
+    if (CACHED && i0 > 0) {                                              // resuming: the two rows above come back from the reconstruction
+        const auto prev = J.recon ? gp(const_cast<const uint8_t *>(J.recon)) : img;      // lossless: the reconstruction IS the input
+        for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
+            uint8_t *dst = rows + (r % 3) * rs;
+            for (int c = lane; c < w; c += 64) dst[c] = prev[size_t(r) * size_t(w) + c];
+        }
+        wave_sync();
+    }
 
-    for (int i = 0; i < h; i++) {
+    for (int i = i0; i < i1; i++) {
         uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
         const size_t row_at = size_t(i) * size_t(w);
         if (CACHED) {                                                    // the row's ORIGINAL pixels; each is replaced by its reconstruction once coded
@@ -450,14 +497,13 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
             const Taps t = CACHED ? tw.taps(w, i, j) : sample_taps(pix, w, i, j);
             const int x = CACHED ? x_next : int(img[row_at + j]);
             if (CACHED) x_next = r0[j + 1 < w ? j + 1 : j];                // the next original pixel: requested a pixel ahead
-            int px0;
-            i64 p1_used = 0;
+            int px0, p1_used = 0;
             if constexpr (N > 0) {
-                if (lane == 0) store_regressors(S.q.vn8, t);
+                store_regressors(S.q.vn8, t);
                 wave_sync();
                 lw.predict(S.q, j);
-                if (lw.ok1) { px0 = int((lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1); p1_used = lw.p1; }
-                else { px0 = predict(t); p1_used = i64(px0) << lsq::kFb1; }
+                if (lw.ok1) { px0 = (lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1; p1_used = lw.p1; }
+                else { px0 = predict(t); p1_used = px0 << lsq::kFb1; }
             } else {
                 px0 = predict(t);
             }
@@ -478,7 +524,7 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
                 if (base + lane <= j) { rec1[row_at + base + lane] = S.rec_ring[lane]; pxs[row_at + base + lane] = S.pxs_ring[lane]; }
             }
             if constexpr (N > 0) {
-                if (lane == 0) S.q.vn8[15] = int8_t(xr - kMid);
+                S.q.vn8[15] = int8_t(xr - kMid);
                 wave_sync();
                 lw.update(S.q, j, xr, p1_used);
                 wave_sync();
@@ -489,6 +535,7 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
             for (int c = lane; c < w; c += 64) recon[row_at + c] = r0[c];
         }
     }
+    if constexpr (N > 0) bias_io = lw.bias;
 }
 
 template <int N>
@@ -496,23 +543,33 @@ __global__ void __launch_bounds__(64) k_serial_model(const SerialJob *__restrict
     __shared__ ModelLds S;
     extern __shared__ __align__(16) uint8_t rows[];
     const SerialJob &J = jobs[blockIdx.x];
+    const auto st = gp(J.state);
+    const auto st_ctx = gp(reinterpret_cast<int *>(J.state + 1));
     const int lane = int(threadIdx.x);
-    for (int k = lane; k < kContexts; k += 64) S.ctx[k] = 0;
+    if (st->status != kRunning) return;                                  // finished in an earlier launch
+    const int i0 = st->next_row, i1 = i0 + J.rows < J.h ? i0 + J.rows : J.h;
+    int bias = i0 ? st->bias : lsq::kBiasInit;
+    for (int k = lane; k < kContexts; k += 64) S.ctx[k] = i0 ? st_ctx[k] : 0;
     fill_qlut(S.qlut);
     if (lane < 16) S.q.vn8[lane] = 0;
     wave_sync();
     const int rs = (J.w + 15) & ~15;
-    if (3 * rs <= dyn_bytes) model_body<N, true>(S, rows, J, rs);
-    else model_body<N, false>(S, rows, J, rs);
+    if (3 * rs <= dyn_bytes) model_body<N, true>(S, rows, J, rs, i0, i1, bias);
+    else model_body<N, false>(S, rows, J, rs, i0, i1, bias);
+    wave_sync();
+    if (i1 < J.h) for (int k = lane; k < kContexts; k += 64) st_ctx[k] = S.ctx[k];
+    if (lane == 0) { st->next_row = i1; st->bias = bias; st->status = i1 < J.h ? kRunning : kDone; }
 }
 
 // ---- decoder: the whole NBLIC loop (NBLIC.c:749-908 with decode = 1) ----------------------------
 // The stream is staged through LDS 512 bytes at a time so that a renormalisation byte costs an LDS
-// read, not a trip to HBM in the middle of the chain.
+// read, not a trip to HBM in the middle of the chain.  `len` is what is PRESENT of the stream (the device
+// copy is padded so that whole 512-byte blocks can be fetched); consuming a byte at or beyond it raises
+// `dry` and returns zeros without moving on, and the caller winds the image up at once.
 struct StreamWindow {
     const uint8_t *base; size_t len, pos;      // pos = next byte to consume
     uint32_t *sbuf;
-    bool overrun;
+    bool dry;
     __device__ void fill_half(size_t from) {   // bytes [from, from + 512) -> sbuf half (from / 512) & 1; from is a multiple of 512
         const auto src = gp(reinterpret_cast<const uint32_t *>(base));       // device copies are 16-byte aligned and padded by 2 KB
         const size_t word = from / 4 + threadIdx.x * 2;
@@ -520,12 +577,12 @@ struct StreamWindow {
         sbuf[((from >> 9) & 1) * 128 + threadIdx.x * 2 + 1] = src[word + 1];
     }
     __device__ void start(const uint8_t *b, size_t n, size_t at, uint32_t *buf) {
-        base = b; len = n; pos = at; sbuf = buf; overrun = false;
+        base = b; len = n; pos = at; sbuf = buf; dry = false;
         fill_half(at & ~size_t(511)); fill_half((at & ~size_t(511)) + 512);
         wave_sync();
     }
     __device__ __forceinline__ uint32_t next() {
-        if (pos >= len) overrun = true;
+        if (pos >= len) { dry = true; return 0u; }
         const uint32_t byte = (sbuf[(pos & 1023) >> 2] >> (8 * (pos & 3))) & 0xFFu;
         pos++;
         if ((pos & 511) == 0) {                 // a half has been consumed: refill it with the bytes 1024 ahead of its start
@@ -537,20 +594,31 @@ struct StreamWindow {
     }
 };
 
+// rows [i0, i1) of the image; coder state in / out through `cs` (lo, hi, window); returns the row it stopped in front of
+// and sets `stop` to kRunning (ran its rows), kStarved, kStarvedMidRow or kFailed
 template <int N, bool CACHED>
-__device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const SerialJob &J, const int rs) {
-    const int w = J.w, h = J.h, lane = int(threadIdx.x), k_step = J.k_step;
+__device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const SerialJob &J, const int rs, const int i0, const int i1,
+                                           StreamWindow &sw, uint32_t (&cs)[3], int &bias_io, const bool final_, int &stop) {
+    const int w = J.w, lane = int(threadIdx.x), k_step = J.k_step;
     const NearParams np = near_params(J.near);
     const uint64_t ktab = level_shift_table(k_step);
     const auto out = gp(J.recon);
     LsqWalk<N> lw;
-    if constexpr (N > 0) lw.init(J.stats, w, lane);
-    StreamWindow sw;
-    sw.start(J.stream, J.stream_len, kHeaderBytes, S.sbuf);
-    uint32_t lo = 0u, hi = 0xFFFFFFFFu, window = 0u;                    // NBLIC.c:536-549
-    for (int k = 0; k < 4; k++) window = (window << 8) | sw.next();
-
-    for (int i = 0; i < h; i++) {
+    if constexpr (N > 0) lw.init(J.stats, w, lane, bias_io);
+    uint32_t lo = cs[0], hi = cs[1], window = cs[2];
+    if (CACHED && i0 > 0) {                                              // resuming: the two rows above come back from the decoded plane
+        for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
+            uint8_t *dst = rows + (r % 3) * rs;
+            for (int c = lane; c < w; c += 64) dst[c] = out[size_t(r) * size_t(w) + c];
+        }
+        wave_sync();
+    }
+    bool damaged = false;
+    int i = i0;
+    stop = kRunning;
+    for (; i < i1; i++) {
+        // a stream that is still being fed: stop in front of a row rather than inside it (serial_engine.h starve_margin)
+        if (!final_ && sw.len - sw.pos < starve_margin(w)) { stop = kStarved; break; }
         uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
         auto pix = [&](int r, int c) {
             if (CACHED) return int((r == i ? r0 : (r == i - 1 ? r1 : r2))[c]);
@@ -563,14 +631,13 @@ __device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const S
         if (CACHED) tw.row_start(r0, r1, r2, w);
         for (int j = 0; j < w; j++) {
             const Taps t = CACHED ? tw.taps(w, i, j) : sample_taps(pix, w, i, j);
-            int px0;
-            i64 p1_used = 0;
+            int px0, p1_used = 0;
             if constexpr (N > 0) {
-                if (lane == 0) store_regressors(S.q.vn8, t);
+                store_regressors(S.q.vn8, t);
                 wave_sync();
                 lw.predict(S.q, j);
-                if (lw.ok1) { px0 = int((lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1); p1_used = lw.p1; }
-                else { px0 = predict(t); p1_used = i64(px0) << lsq::kFb1; }
+                if (lw.ok1) { px0 = (lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1; p1_used = lw.p1; }
+                else { px0 = predict(t); p1_used = px0 << lsq::kFb1; }
             } else {
                 px0 = predict(t);
             }
@@ -588,11 +655,11 @@ __device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const S
                 const int prob = mix_prob(prob_one(u0, u1), prob_one(v0, v1), L.qw);
                 const uint32_t cut = lo + uint32_t((u64(hi - lo) * uint32_t(prob)) >> 12);
                 // a symbol of a valid stream has well under a hundred bins; a damaged one (all ones) could walk for ever:
-                // from the 512th bin of a pixel on, and past the end of the stream, every symbol ends at once
-                if (++bins_px > 512) sw.overrun = true;
-                const int bin = sw.overrun ? 0 : int(window <= cut);
+                // from the 512th bin of a pixel on, and once the stream has run dry, every symbol ends at once
+                if (++bins_px > 512) damaged = true;
+                const int bin = (sw.dry | damaged) ? 0 : int(window <= cut);
                 if (bin) hi = cut; else lo = cut + 1;
-                while (((lo ^ hi) >> 24) == 0) { window = (window << 8) | sw.next(); lo <<= 8; hi = (hi << 8) | 0xFFu; }
+                while (((lo ^ hi) >> 24) == 0 && !sw.dry) { window = (window << 8) | sw.next(); lo <<= 8; hi = (hi << 8) | 0xFFu; }
                 Counter a{u0, u1};
                 counter_add(a, bin, kWeightOne - L.qw);
                 if (qu == qv) counter_add(a, bin, L.qw);                 // same counter takes both weights
@@ -604,6 +671,7 @@ __device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const S
                 }
                 return bin;
             });
+            if (sw.dry | damaged) break;                                 // the image cannot be finished from here: no pixel is written for this symbol
             const int y = z < kMapSyms ? int(S.sym_at[mk][z]) : z;
             if (y < kMapSyms) {                                          // NBLIC.c:497-523 (z is y's rank)
                 const int c = S.count[mk][z] + 1;
@@ -622,18 +690,21 @@ __device__ __forceinline__ void decode_body(DecodeLds &S, uint8_t *rows, const S
             S.ctx[adr] = bias_update(v, err);
             if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else { out[row_at + j] = uint8_t(xr); __threadfence_block(); }
             if constexpr (N > 0) {
-                if (lane == 0) S.q.vn8[15] = int8_t(xr - kMid);
+                S.q.vn8[15] = int8_t(xr - kMid);
                 wave_sync();
                 lw.update(S.q, j, xr, p1_used);
                 wave_sync();
             }
         }
+        if (sw.dry | damaged) { stop = (damaged || final_) ? kFailed : kStarvedMidRow; break; }
         if (CACHED) {
             wave_sync();
             for (int c = lane; c < w; c += 64) out[row_at + c] = r0[c];
         }
     }
-    if (lane == 0) *J.status = sw.overrun ? -1 : 0;
+    cs[0] = lo; cs[1] = hi; cs[2] = window;
+    if constexpr (N > 0) bias_io = lw.bias;
+    return i;
 }
 
 template <int N>
@@ -641,19 +712,54 @@ __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restric
     __shared__ DecodeLds S;
     extern __shared__ __align__(16) uint8_t rows[];
     const SerialJob &J = jobs[blockIdx.x];
+    const auto st = gp(J.state);
+    const auto st_tab = gp(reinterpret_cast<uint32_t *>(J.state + 1));
+    constexpr int kTabWords = int((kDecodeStateBytes - sizeof(SerialState)) / 4);
+    uint32_t *lds_tab = reinterpret_cast<uint32_t *>(&S);
     const int lane = int(threadIdx.x);
-    for (int k = lane; k < kContexts; k += 64) S.ctx[k] = 0;
-    for (int k = lane; k < kLevels * kTreeNodes; k += 64) (&S.cnt[0][0])[k] = uint32_t(kWeightOne) | (uint32_t(kWeightOne) << 16);
-    for (int k = lane; k < 512 * kMapSyms; k += 64) {
-        const int s = k % kMapSyms;
-        (&S.count[0][0])[k] = 2 * (kMapSyms - 1 - s); (&S.rank_of[0][0])[k] = uint8_t(s); (&S.sym_at[0][0])[k] = uint8_t(s);
+    if (st->status != kRunning) return;                                  // finished, failed, or waiting for the host to feed the stream
+    const int i0 = st->next_row, i1 = i0 + J.rows < J.h ? i0 + J.rows : J.h;
+    const bool final_ = st->final_ != 0;
+    const size_t avail = size_t(st->avail);
+    if (!final_ && avail < size_t(kHeaderBytes) + 4 + starve_margin(J.w) && i0 == 0) {       // not even the start of the stream is there yet
+        if (lane == 0) st->status = kStarved;
+        return;
+    }
+    if (i0 == 0) {
+        for (int k = lane; k < kContexts; k += 64) S.ctx[k] = 0;
+        for (int k = lane; k < kLevels * kTreeNodes; k += 64) (&S.cnt[0][0])[k] = uint32_t(kWeightOne) | (uint32_t(kWeightOne) << 16);
+        for (int k = lane; k < 512 * kMapSyms; k += 64) {
+            const int s = k % kMapSyms;
+            (&S.count[0][0])[k] = 2 * (kMapSyms - 1 - s); (&S.rank_of[0][0])[k] = uint8_t(s); (&S.sym_at[0][0])[k] = uint8_t(s);
+        }
+    } else {
+        for (int k = lane; k < kTabWords; k += 64) lds_tab[k] = st_tab[k];
     }
     fill_qlut(S.qlut);
     if (lane < 16) S.q.vn8[lane] = 0;
     wave_sync();
+    StreamWindow sw;
+    uint32_t cs[3] = {0u, 0xFFFFFFFFu, 0u};                              // NBLIC.c:536-549
+    int bias = lsq::kBiasInit;
+    if (i0 == 0) {
+        sw.start(J.stream, avail, kHeaderBytes, S.sbuf);
+        for (int k = 0; k < 4; k++) cs[2] = (cs[2] << 8) | sw.next();
+    } else {
+        sw.start(J.stream, avail, size_t(st->pos), S.sbuf);
+        cs[0] = st->lo; cs[1] = st->hi; cs[2] = st->window; bias = st->bias;
+    }
     const int rs = (J.w + 15) & ~15;
-    if (3 * rs <= dyn_bytes) decode_body<N, true>(S, rows, J, rs);
-    else decode_body<N, false>(S, rows, J, rs);
+    int stop = kRunning, at;
+    if (sw.dry) { stop = kFailed; at = i0; }                             // a final stream shorter than its own start
+    else if (3 * rs <= dyn_bytes) at = decode_body<N, true>(S, rows, J, rs, i0, i1, sw, cs, bias, final_, stop);
+    else at = decode_body<N, false>(S, rows, J, rs, i0, i1, sw, cs, bias, final_, stop);
+    wave_sync();
+    if (stop == kFailed || stop == kStarvedMidRow) { if (lane == 0) st->status = stop; return; }
+    if (at < J.h) for (int k = lane; k < kTabWords; k += 64) st_tab[k] = lds_tab[k];
+    if (lane == 0) {
+        st->next_row = at; st->pos = sw.pos; st->lo = cs[0]; st->hi = cs[1]; st->window = cs[2]; st->bias = bias;
+        st->status = at >= J.h ? kDone : stop;                           // kRunning (more rows to go) or kStarved (feed me)
+    }
 }
 
 // ---- QNBLIC decoder (QNBLIC.c:493-555): one image per wave, every lane computing the same pixel -------
@@ -663,6 +769,8 @@ __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restric
 // of the 384 KB slot table in memory on the pixel's critical path.  Taps: rows >= 2 use the sliding window
 // (QNBLIC's window neighbourhood equals direct sampling there except a / e at the row start);
 // rows 0 and 1 use the closed form of model.h sample_taps_q.
+// Resumable like the others; a pixel consumes at most one 16-bit word, so a row never needs more than 2 w bytes
+// and a stream that is still being fed is only ever left in front of a row (kStarved).
 struct QDecodeLds {
     int ctx[3072];
     uint16_t freq[12 * 256], start[12 * 256 + 1];
@@ -674,10 +782,17 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restri
     __shared__ QDecodeLds S;
     extern __shared__ __align__(16) uint8_t rows[];
     const SerialJob &J = jobs[blockIdx.x];
+    const auto st = gp(J.state);
+    const auto st_ctx = gp(reinterpret_cast<int *>(J.state + 1));
     const int lane = int(threadIdx.x), w = J.w, h = J.h;
     const auto out = gp(J.recon);
+    if (st->status != kRunning) return;
+    const int i0 = st->next_row, i1 = i0 + J.rows < h ? i0 + J.rows : h;
+    const bool final_ = st->final_ != 0;
+    const size_t avail = size_t(st->avail) & ~size_t(1), row_need = size_t(2) * size_t(w) + 8;
+    if (!final_ && (avail < size_t(st->pos) || avail - size_t(st->pos) < row_need)) { if (lane == 0) st->status = kStarved; return; }
     for (int k = lane; k < 3072; k += 64) {
-        S.ctx[k] = 0; S.freq[k] = uint16_t(gp(J.q_freq)[k]); S.start[k] = uint16_t(gp(J.q_start)[k]);
+        S.ctx[k] = i0 ? st_ctx[k] : 0; S.freq[k] = uint16_t(gp(J.q_freq)[k]); S.start[k] = uint16_t(gp(J.q_start)[k]);
         (&S.coarse[0][0])[k] = gp(J.q_slot)[size_t(k >> 8) * 32768 + size_t(k & 255) * 128];
     }
     if (lane == 0) S.start[3072] = 0;
@@ -685,11 +800,21 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restri
     const int rs = (w + 15) & ~15;
     const bool cached = 3 * rs <= dyn_bytes;
     StreamWindow sw;
-    sw.start(J.stream, J.q_words * 2, J.q_pos * 2, S.sbuf);
+    sw.start(J.stream, avail, size_t(st->pos), S.sbuf);                   // a fresh image: the host has set pos to the first word after the tables
     auto next_word = [&]() { const uint32_t lo = sw.next(); return lo | (sw.next() << 8); };
-    uint32_t x = next_word() << 16;
-    x |= next_word();
-    for (int i = 0; i < h; i++) {
+    uint32_t x;
+    if (i0 == 0) { x = next_word() << 16; x |= next_word(); }
+    else x = st->lo;
+    if (cached && i0 > 0) {
+        for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
+            uint8_t *dst = rows + (r % 3) * rs;
+            for (int c = lane; c < w; c += 64) dst[c] = out[size_t(r) * size_t(w) + c];
+        }
+        wave_sync();
+    }
+    int i = i0, stop = kRunning;
+    for (; i < i1; i++) {
+        if (!final_ && sw.len - sw.pos < row_need) { stop = kStarved; break; }
         uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
         auto pix = [&](int r, int c) {
             if (cached) return int((r == i ? r0 : (r == i - 1 ? r1 : r2))[c]);
@@ -723,15 +848,18 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restri
             err = px_out - px0;
             S.ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
             if (cached) { r0[j] = uint8_t(px_out); if (windowed) tw.advance(r1, r2, w, j, px_out); } else { out[row_at + j] = uint8_t(px_out); __threadfence_block(); }
-            if (sw.overrun) break;
+            if (sw.dry) break;
         }
+        if (sw.dry) { stop = kFailed; break; }                           // only a final stream can run dry inside a row (see above)
         if (cached) {
             wave_sync();
             for (int c = lane; c < w; c += 64) out[row_at + c] = r0[c];
         }
-        if (sw.overrun) break;
     }
-    if (lane == 0) *J.status = (sw.overrun || J.q_words == 0) ? -1 : 0;
+    wave_sync();
+    if (stop == kFailed || sw.dry) { if (lane == 0) st->status = kFailed; return; }
+    if (i < h) for (int k = lane; k < 3072; k += 64) st_ctx[k] = S.ctx[k];
+    if (lane == 0) { st->next_row = i; st->pos = sw.pos; st->lo = x; st->status = i >= h ? kDone : stop; }
 }
 
 // ---- self-test: the double-carried divisions against 64-bit integers ------------------------------
@@ -747,6 +875,15 @@ __global__ void k_selftest_div(const i64 *a, const i64 *b, const i64 *d, int n, 
     if (i64(got) != want) atomicAdd(bad, 1u);
     const i64 v = a[t] >> 4;
     if (i64(lsq::decay<5>(double(v))) != (v * 4 + 2) / 5 || i64(lsq::decay<3>(double(v))) != (v * 2 + 1) / 3) atomicAdd(bad, 1u);
+}
+
+// the half-wave exchange the split solve relies on: lane L must see lane (L & 31) + 32 * HALF's value
+__global__ void k_selftest_swap(uint32_t *bad) {
+    const int lane = int(threadIdx.x);
+    const double v = 1000.0 * double(blockIdx.x + 1) + double(lane) + 0.25;
+    const double lo = bcast_half<0>(v), hi = bcast_half<1>(v);
+    const double base = 1000.0 * double(blockIdx.x + 1) + 0.25;
+    if (lo != base + double(lane & 31) || hi != base + double((lane & 31) + 32)) atomicAdd(bad, 1u);
 }
 
 int serial_selftest(hipStream_t s) {
@@ -770,6 +907,7 @@ int serial_selftest(hipStream_t s) {
     hipMemcpyAsync(dv, h, 3 * n * sizeof(i64), hipMemcpyHostToDevice, s);
     hipMemsetAsync(d_bad, 0, 4, s);
     hipLaunchKernelGGL(k_selftest_div, dim3(n / 256), dim3(256), 0, s, dv, dv + n, dv + 2 * n, n, d_bad);
+    hipLaunchKernelGGL(k_selftest_swap, dim3(4), dim3(64), 0, s, d_bad);
     hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s);
     hipStreamSynchronize(s);
     hipFree(dv); hipFree(d_bad); free(h);
@@ -778,12 +916,15 @@ int serial_selftest(hipStream_t s) {
 
 // ---- launchers ----------------------------------------------------------------------------------
 constexpr int kLdsBudget = 160 * 1024;
+constexpr int lds_room(size_t static_lds) { return int(kLdsBudget - static_lds - 256) & ~15; }
+
+bool serial_model_rows_fit(int w) { return 3 * ((w + 15) & ~15) <= lds_room(sizeof(ModelLds)); }
 
 template <class K>
 static bool launch_rows(K kernel, size_t static_lds, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
     int max_w = 1;
     for (int k = 0; k < n; k++) max_w = h_jobs[k].w > max_w ? h_jobs[k].w : max_w;
-    const int room = int(kLdsBudget - static_lds - 256) & ~15;
+    const int room = lds_room(static_lds);
     int dyn = 3 * ((max_w + 15) & ~15);
     if (dyn > room) dyn = room;                  // wider images fall back to taps from memory (the kernel compares per job)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) return false;
