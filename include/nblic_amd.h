@@ -161,6 +161,35 @@ void nblic_amd_set_max_pixels(nblic_amd_ctx *ctx, long max_pixels);
 void nblic_amd_set_serial_rows(nblic_amd_ctx *ctx, int rows);
 long nblic_amd_serial_launches(nblic_amd_ctx *ctx);
 
+/* ONE image of any mode, worked through in ROW BANDS (src/NBLIC.c:749-908 is one loop over the rows; every piece of
+ * state it carries from row to row is small).  Per band: the model stage for the band's rows, the entropy stages for
+ * those pixels (their adaptive tables carried from band to band), the band's bins through the range coder.  The device
+ * workspace is one band's whatever the image size, no kernel runs longer than a band, and between two bands the
+ * encoder can be SUSPENDED: nblic_amd_stream_checkpoint writes down everything it carries (a few hundred KB plus
+ * 8 * width * (1 + n + n^2) bytes of least-squares statistics at efforts 2 / 3), nblic_amd_stream_resume -- in
+ * another call, another process, on another GPU -- carries on from there.  The stream's bytes are identical to
+ * NBLICcompress's.  A running SHA-256 of the bytes emitted travels with the checkpoint, so a run that never holds the
+ * whole stream in one place can still be checked against a golden hash.
+ *   _begin    img: the whole plane (host or device; it must stay valid until _end).  band_rows <= 0: sized automatically.
+ *             Takes one group of the context until _end.  NULL on failure.
+ *   _run      codes bands until the image is finished (returns 1) or budget_seconds (> 0) have passed (returns 0); the
+ *             stream bytes produced by THIS call are written to out (out_cap is checked, -1 if too small) and counted
+ *             in *out_len: concatenate the pieces of successive calls.
+ *   _progress rows finished, bytes emitted so far, their SHA-256, milliseconds spent in the model kernel; returns 1 / 0 / -1.
+ *   _checkpoint  writes the checkpoint into buf (cap bytes) and returns its size; with buf == NULL or cap too small it
+ *             only returns the size needed.  Valid between two _run calls.
+ *   _recon    after the image is finished: the reconstruction the reference leaves in p_img (NBLIC.c:876).            */
+typedef struct nblic_amd_stream nblic_amd_stream;
+nblic_amd_stream *nblic_amd_stream_begin(nblic_amd_ctx *ctx, const unsigned char *img, int img_on_device, int height, int width,
+                                         int near, int effort, int band_rows);
+nblic_amd_stream *nblic_amd_stream_resume(nblic_amd_ctx *ctx, const unsigned char *img, int img_on_device, const void *checkpoint,
+                                          size_t checkpoint_bytes);
+int nblic_amd_stream_run(nblic_amd_stream *s, double budget_seconds, unsigned char *out, size_t out_cap, size_t *out_len);
+size_t nblic_amd_stream_checkpoint(nblic_amd_stream *s, void *buf, size_t cap);
+int nblic_amd_stream_progress(nblic_amd_stream *s, int *rows_done, unsigned long long *bytes_total, unsigned char sha256[32], double *model_ms);
+int nblic_amd_stream_recon(nblic_amd_stream *s, unsigned char *recon);
+void nblic_amd_stream_end(nblic_amd_stream *s);
+
 /* The reference's decoders take no stream length (src/NBLIC.h:72, src/QNBLIC.h:16).  NBLICdecompress / QNBLICdecompress
  * therefore fetch the caller's stream ON DEMAND in steps of `bytes` (default 1 MiB, at least 4096): the decoder stops in
  * front of a row when it is about to run short, the next step is copied in, it resumes.  No byte beyond the last one the

@@ -39,6 +39,8 @@ EXPORTS = (
     "nblic_amd_enable_timing", "nblic_amd_stage_times", "nblic_amd_last_launches", "nblic_amd_last_stats", "nblic_amd_debug_stage",
     "nblic_amd_encode_batch_modes", "nblic_amd_decode_batch", "nblic_amd_serial_selftest",
     "nblic_amd_set_serial_rows", "nblic_amd_serial_launches", "nblic_amd_set_feed_chunk", "nblic_amd_last_fed_bytes",
+    "nblic_amd_stream_begin", "nblic_amd_stream_resume", "nblic_amd_stream_run", "nblic_amd_stream_checkpoint", "nblic_amd_stream_progress",
+    "nblic_amd_stream_recon", "nblic_amd_stream_end",
     "nblic_amd_cli_main", "nblic_amd_cli_parse", "nblic_amd_read_gray", "nblic_amd_write_gray",
     "nblic_amd_set_device_coder", "nblic_amd_device_coder_stats",
     "nblic_amd_range_code", "nblic_amd_range_code_multi", "nblic_amd_range_code_chunked", "nblic_amd_selftest", "nblic_amd_syn1", "nblic_amd_version",
@@ -124,6 +126,20 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_set_feed_chunk.argtypes = [C.c_void_p, C.c_size_t]
     lib.nblic_amd_last_fed_bytes.restype = C.c_long
     lib.nblic_amd_last_fed_bytes.argtypes = [C.c_void_p]
+    lib.nblic_amd_stream_begin.restype = C.c_void_p
+    lib.nblic_amd_stream_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.nblic_amd_stream_resume.restype = C.c_void_p
+    lib.nblic_amd_stream_resume.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.nblic_amd_stream_run.restype = C.c_int
+    lib.nblic_amd_stream_run.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.nblic_amd_stream_checkpoint.restype = C.c_size_t
+    lib.nblic_amd_stream_checkpoint.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.nblic_amd_stream_progress.restype = C.c_int
+    lib.nblic_amd_stream_progress.argtypes = [C.c_void_p, ip, C.POINTER(C.c_ulonglong), C.c_void_p, C.POINTER(C.c_double)]
+    lib.nblic_amd_stream_recon.restype = C.c_int
+    lib.nblic_amd_stream_recon.argtypes = [C.c_void_p, C.c_void_p]
+    lib.nblic_amd_stream_end.restype = None
+    lib.nblic_amd_stream_end.argtypes = [C.c_void_p]
     lib.nblic_amd_enable_timing.restype = None
     lib.nblic_amd_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.nblic_amd_stage_times.restype = C.c_int
@@ -428,6 +444,10 @@ class Context:
     def set_max_pixels(self, n: int):
         self.lib.nblic_amd_set_max_pixels(self.handle, n)
 
+    def stream(self, img: np.ndarray, near: int, effort: int, band_rows: int = 0, checkpoint: Optional[bytes] = None) -> "BandStream":
+        """One image in row bands (``nblic_amd_stream_*``): bounded workspace, suspend / resume through checkpoints."""
+        return BandStream(self, img, near, effort, band_rows, checkpoint)
+
     def set_serial_rows(self, rows: int):
         """Rows per launch of the resumable serial kernels (``nblic_amd_set_serial_rows``); 0 = automatic."""
         self.lib.nblic_amd_set_serial_rows(self.handle, rows)
@@ -545,3 +565,58 @@ class Context:
         if cnt < 0:
             raise RuntimeError("nblic_amd_debug_stage failed")
         return out[:cnt].copy()
+
+
+class BandStream:
+    """An encode in progress (``nblic_amd_stream``).  ``run(budget_seconds)`` returns (finished, bytes of this call);
+    ``checkpoint()`` the state to hand to ``Context.stream(..., checkpoint=...)`` in another call or process."""
+
+    def __init__(self, ctx: Context, img: np.ndarray, near: int, effort: int, band_rows: int = 0, checkpoint: Optional[bytes] = None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.img = np.ascontiguousarray(img, np.uint8)
+        h, w = self.img.shape
+        if checkpoint is None:
+            self.handle = self.lib.nblic_amd_stream_begin(ctx.handle, C.c_void_p(self.img.ctypes.data), 0, h, w, near, effort, band_rows)
+        else:
+            self._ck = np.frombuffer(bytes(checkpoint), np.uint8).copy()
+            self.handle = self.lib.nblic_amd_stream_resume(ctx.handle, C.c_void_p(self.img.ctypes.data), 0, C.c_void_p(self._ck.ctypes.data), self._ck.size)
+        if not self.handle:
+            raise RuntimeError("nblic_amd_stream_begin / _resume failed")
+        self.out = np.empty(h * w + h * w // 8 + 65536, np.uint8)
+
+    def run(self, budget_seconds: float = 0.0) -> Tuple[bool, bytes]:
+        n = C.c_size_t(0)
+        rc = self.lib.nblic_amd_stream_run(self.handle, float(budget_seconds), C.c_void_p(self.out.ctypes.data), self.out.size, C.byref(n))
+        if rc < 0:
+            raise RuntimeError("nblic_amd_stream_run failed")
+        return rc == 1, self.out[: n.value].tobytes()
+
+    def progress(self) -> dict:
+        rows, total, ms = C.c_int(), C.c_ulonglong(), C.c_double()
+        digest = (C.c_ubyte * 32)()
+        state = self.lib.nblic_amd_stream_progress(self.handle, C.byref(rows), C.byref(total), digest, C.byref(ms))
+        return {"state": state, "rows_done": rows.value, "bytes_total": total.value, "sha256": bytes(digest).hex(), "model_kernel_ms": ms.value}
+
+    def checkpoint(self) -> bytes:
+        need = self.lib.nblic_amd_stream_checkpoint(self.handle, None, 0)
+        buf = np.empty(need, np.uint8)
+        if self.lib.nblic_amd_stream_checkpoint(self.handle, C.c_void_p(buf.ctypes.data), need) != need:
+            raise RuntimeError("nblic_amd_stream_checkpoint failed")
+        return buf.tobytes()
+
+    def recon(self) -> np.ndarray:
+        rec = np.empty_like(self.img)
+        if self.lib.nblic_amd_stream_recon(self.handle, C.c_void_p(rec.ctypes.data)) != 0:
+            raise RuntimeError("nblic_amd_stream_recon: the image is not finished")
+        return rec
+
+    def close(self):
+        if self.handle:
+            self.lib.nblic_amd_stream_end(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

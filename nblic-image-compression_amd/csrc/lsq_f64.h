@@ -57,72 +57,82 @@ LSQ_HD double max_abs(double a, double b) {
 #endif
 }
 struct Guard {
-    double product = 0.0, entry = 0.0, quotient = 0.0;
+    double product = 0.0, entry = 0.0, quotient = 0.0, pivot = 0.0;
     LSQ_HD void see_product(double v) { product = max_abs(product, v); }
     LSQ_HD void see_entry(double v) { entry = max_abs(entry, v); }
     LSQ_HD void see_quotient(double v) { quotient = max_abs(quotient, v); }
+    LSQ_HD void see_pivot(double v) { pivot = max_abs(pivot, v); }
     // 2^62: beyond it the reference's int64 product may wrap; 2^44: entries stay exact and the pivot key (|v| * 256 + tag)
-    // fits 53 bits; 2^46: an estimate this large may be off by more than one
-    LSQ_HD bool ok() const { return product < 4611686018427387904.0 && entry < 17592186044416.0 && quotient < 70368744177664.0; }
+    // fits 53 bits; 2^46: an estimate this large may be off by more than one; 2^38: a divisor this large defeats the
+    // one-multiply correction below
+    LSQ_HD bool ok() const {
+        return product < 4611686018427387904.0 && entry < 17592186044416.0 && quotient < 70368744177664.0 && pivot < 274877906944.0;
+    }
 };
 
 // ---- truncating division by estimate + exact remainder -------------------------------------------
-// The estimate is made with a reciprocal that is deliberately SHORT by a factor (1 - 2^-48): then
-// |trunc(estimate)| is never above |trunc(true quotient)| and at most one below it while the quotient
-// is below 2^46, so a single one-sided correction (is the remainder still >= |d| ?) finishes it, and
-// the reciprocal itself needs no more than ~2^-50 relative accuracy (hardware seed + two Newton
-// steps on the device; checked there by nblic_amd_serial_selftest).
+// The estimate q0 = trunc(n * rs) is made with a reciprocal that is deliberately SHORT by a factor (1 - 2^-48): then
+// |q0| is never above |trunc(n / d)| and at most one below it while the quotient is below 2^46.  The remainder
+// r = n - q0 d is exact (a fused multiply-add), has the sign of n and |r| <= 2|d| - 1; what is left to decide is
+// whether |r| >= |d|, and with which sign the quotient moves.  Both at once: trunc(r * rl) with a reciprocal that is
+// LONG by (1 + 2^-40).  For |r| >= |d| the product is >= 1 + 2^-41 in magnitude and, because |r / d| <= 2 - 1/|d|,
+// below 2 while |d| < 2^38.9; for |r| < |d| it is at most (1 - 1/|d|)(1 + 2^-40 + ...) < 1 while |d| < 2^39.9; its sign is
+// that of r * d = that of n * d.  So the correction is ONE multiply and ONE truncation -- no compare, no select, no sign
+// logic (that was five operations per quotient, forty-four quotients per pixel) -- for divisors below 2^38, which the
+// caller guarantees (Guard::see_pivot; the pivots of these systems are ~2^25).  The raw reciprocal needs ~2^-49
+// relative accuracy (hardware seed + two Newton steps on the device; checked there by nblic_amd_serial_selftest).
 constexpr double kShort = 1.0 - 3.5527136788005009e-15;               // 1 - 2^-48
+constexpr double kLong = 1.0 + 9.0949470177292824e-13;                // 1 + 2^-40
 
-LSQ_HD double recip_short(double d) {
+LSQ_HD double recip_raw(double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double r = __builtin_amdgcn_rcp(d);
     r = fma(fma(-d, r, 1.0), r, r);
     r = fma(fma(-d, r, 1.0), r, r);
-    return r * kShort;
+    return r;
 #else
-    return (1.0 / d) * kShort;
+    return 1.0 / d;
 #endif
 }
+struct Recip { double s, l; };                                         // the short and the long reciprocal of one divisor
+LSQ_HD Recip recip_of_raw(double raw) { return Recip{raw * kShort, raw * kLong}; }
+LSQ_HD Recip recip_of(double d) { return recip_of_raw(recip_raw(d)); }
 
-// The one-sided correction of an estimated quotient: +-1.0 (the sign of n * d) when the remainder r of the estimate
-// is still as large as the divisor, else 0.  On the device the select is spelled out (a compare into vcc and ONE
-// conditional move of a float unit, widened afterwards): left to itself the compiler turns the rare correction into
-// an exec-masked block around three integer operations -- two scalar instructions and a pipeline bubble per quotient,
-// forty-four times per pixel.
-LSQ_HD double fix_up(double r, double d, double n) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int unit = ((__double2hiint(n) ^ __double2hiint(d)) & int(0x80000000u)) | 0x3F800000;      // +-1.0f
-    float c;
-    asm("v_cmp_ge_f64 vcc, |%1|, |%2|\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(c) : "v"(r), "v"(d), "v"(unit) : "vcc");
-    return double(c);
-#else
-    return fabs(r) >= fabs(d) ? copysign(1.0, n) * copysign(1.0, d) : 0.0;
-#endif
-}
-
-// trunc(n / d) for an integer-valued n with |n| < 2^53; rs = recip_short(d).  Exact while |n / d| < 2^46.
-LSQ_HD double div_trunc(double n, double d, double rs) {
-    const double q0 = trunc(n * rs);
+// trunc(n / d) for an integer-valued n with |n| < 2^53 and |d| < 2^38.  Exact while |n / d| < 2^46.
+LSQ_HD double div_trunc(double n, double d, const Recip &rc) {
+    const double q0 = trunc(n * rc.s);
     const double r = fma(-q0, d, n);                     // exact; same sign as n, |r| < 2|d|
-    return q0 + fix_up(r, d, n);
+    return q0 + trunc(r * rc.l);
 }
 
-// trunc(a * b / d) with the product carried exactly as p + e (|a b| may exceed 2^53).
-LSQ_HD double muldiv_trunc(double a, double b, double d, double rs, Guard &g) {
+// trunc(a * b / d) with the product carried exactly as p + e (|a b| may exceed 2^53); |d| < 2^38.
+LSQ_HD double muldiv_trunc(double a, double b, double d, const Recip &rc, Guard &g) {
     const double p = a * b;
     const double e = fma(a, b, -p);                      // a*b == p + e exactly
-    const double q0 = trunc(p * rs);
+    const double q0 = trunc(p * rc.s);
     const double r = fma(-q0, d, p) + e;                 // exact remainder of the estimate
     g.see_product(p);
-    return q0 + fix_up(r, d, p);
+    return q0 + trunc(r * rc.l);
 }
 
-// (v * (ab-1) + ab/2) / ab, truncating (NBLIC.c:199, :273-279); |v| < 2^44
+// ---- truncating division of a statistic by a small divisor: one multiply ---------------------------
+// trunc(n / c) for an integer n and an integer divisor c >= 1 with |n / c| * 2^-49 < 0.5 / c:  n = k c + r (0 <= r < c,
+// magnitudes) gives (|n| + 0.5) / c = k + (r + 0.5) / c, whose fractional part lies in [0.5 / c, 1 - 0.5 / c]: the
+// product with a reciprocal of relative error e lands on the right side of both integers as long as (k + 1) e < 0.5 / c.
+//   decays (c = 3, 5; |n| < 2^47; exactly rounded 1 / c):   2^47 * 2^-52 = 2^-5 < 0.1
+//   samples (c = s <= 2^16; |n / s| <= 2^30; device reciprocal, e < 2^-49):   2^30 * 2^-49 = 2^-19 < 2^-17
+LSQ_HD double half_toward(double n) {                     // n + 0.5 with n's sign (n == 0 counts as positive)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return n + __hiloint2double((__double2hiint(n) & int(0x80000000u)) | 0x3FE00000, 0);
+#else
+    return n + copysign(0.5, n);
+#endif
+}
+// (v * (ab-1) + ab/2) / ab, truncating (NBLIC.c:199, :273-279); |v| < 2^44.  The numerator has v's sign (it is ab/2 > 0 for v = 0).
 template <int AB>
 LSQ_HD double decay(double v) {
     const double n = fma(v, double(AB - 1), double(AB / 2));
-    return div_trunc(n, double(AB), kShort / double(AB));
+    return trunc(half_toward(n) * (1.0 / double(AB)));
 }
 LSQ_HD double decay_k(double v, int k) { return k ? decay<kDecayV>(v) : decay<kDecayS>(v); }
 
@@ -133,22 +143,21 @@ LSQ_HD double sample_weight(double s_sum) {
 }
 
 // one entry of the new sample (NBLIC.c:253-267): (prod << shift + s/2) / s with prod = (x-128)*vn_k
-// (shift 28) or vn_j*vn_k (shift 18); |prod| <= 2^14
-LSQ_HD double sample_entry(int prod, double scale, double s, double rs) {     // rs = recip_short(s)
+// (shift 28) or vn_j*vn_k (shift 18); |prod| <= 2^14, s in [2^12, 2^16]; r = recip_raw(s)
+LSQ_HD double sample_entry(int prod, double scale, double s, double r) {
     const double n = fma(double(prod), scale, floor(s * 0.5));
-    return div_trunc(n, s, rs);
+    return trunc(half_toward(n) * r);
 }
 constexpr double kScaleB = 268435456.0;                  // 1 << (4 + FB1 + FB1)
 constexpr double kScaleA = 262144.0;                     // 1 << (4 + FB2 + FB1)
 
 // contribution of coefficient k to the Q12 prediction (NBLIC.c:233-236): (b*vn*4 + (d >> 1)) / d
-LSQ_HD double term(double b, int vn, double d, double rs, Guard &g) {                  // rs = recip_short(d)
+LSQ_HD double term(double b, int vn, double d, const Recip &rc, Guard &g) {
     const double n = fma(b, double(vn * (1 << kFb2)), floor(d * 0.5));
-    g.see_quotient(n * rs);
+    g.see_quotient(n * rc.s);
     g.see_entry(b);
-    return div_trunc(n, d, rs);
+    return div_trunc(n, d, rc);
 }
-LSQ_HD double term(double b, int vn, double d, Guard &g) { return term(b, vn, d, recip_short(d), g); }
 
 // the two candidate regularisation strengths around `bias` (NBLIC.c:837-842)
 LSQ_HD void bias_pair(int bias, int &b1, int &b2) {

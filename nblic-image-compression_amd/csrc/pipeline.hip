@@ -37,6 +37,7 @@
 #include "model.h"
 #include "range_coder.h"
 #include "serial_engine.h"
+#include "sha256.h"
 
 struct nblic_amd_ctx;
 
@@ -1347,9 +1348,17 @@ static bool decode_batch(nblic_amd_ctx *c, int n, const unsigned char *const *st
 // exactly to its last byte.
 static size_t safe_copy(nblic_amd_ctx *c, void *dst, const void *src, size_t n) {
     if (c->feed_pipe[0] < 0 && pipe(c->feed_pipe) != 0) { c->feed_pipe[0] = c->feed_pipe[1] = -1; return 0; }
+    const size_t page = size_t(sysconf(_SC_PAGESIZE));
     size_t done = 0;
     while (done < n) {
-        const size_t want = n - done < 65536 ? n - done : 65536;                    // a fresh pipe holds 64 KB: the write never blocks
+        // The pipe takes a write in page-sized pieces and DROPS a piece it could only copy in part, so the pieces have to
+        // coincide with the source's pages: first the bytes up to the next page boundary, then whole pages (64 KB at a time:
+        // what a fresh pipe holds, so the write never blocks).  A write that comes back short then ends exactly where the
+        // readable memory ends.
+        const size_t addr = size_t(reinterpret_cast<uintptr_t>(src)) + done;
+        const size_t to_boundary = page - (addr & (page - 1));
+        size_t want = (addr & (page - 1)) ? to_boundary : size_t(65536);
+        if (want > n - done) want = n - done;
         const ssize_t k = write(c->feed_pipe[1], static_cast<const char *>(src) + done, want);
         if (k <= 0) break;                                                          // EFAULT: not one more byte can be read
         size_t got = 0;
@@ -1453,6 +1462,224 @@ static int decode_fed(nblic_amd_ctx *c, const unsigned char *p, bool qnblic, uns
         final_ = true;
     }
     return -1;
+}
+
+// ---- one image in ROW BANDS: bounded workspace, bounded launches, suspend and resume ----------------
+// The serial modes' model stage is resumable row by row (serial_engine.h), and the entropy stages carry their
+// adaptive state -- the 512 re-mappers, the 4096 counters -- in small per-image tables from launch to launch
+// (kernels_e1.hip k_mapper_chains / k_counter_epochs read and write map_state / cnt_state).  So an image of any
+// size can be worked through band by band: model stage for the band's rows -> re-mapper partition and chains,
+// binarisation, counter partition, epochs, probabilities, mix for THOSE pixels -> the band's coded bins to the
+// host -> the range coder, which is resumable too, carries on.  The device workspace is that of one band
+// (config 5 of BASELINE.json, 268 Mpixel at effort 3, would need 32 GB in one piece), no kernel runs longer than
+// a band, and between bands EVERYTHING the encoder carries is small enough to be written down: a checkpoint
+// (model state record, the least-squares column statistics, the two tables, the coder interval, a running SHA-256
+// of the bytes emitted so far) from which another call -- another process -- carries on.
+struct BandCheckpoint {                 // followed by: model state record | B statistics | map_state | cnt_state | two reconstruction rows (if kept)
+    char magic[8];                      // "NBLCKPT1"
+    int h, w, near, effort, band_rows, next_row;
+    uint32_t lo, hi;                    // coder interval (NBLIC.c:527-533)
+    unsigned long long bytes_total;     // stream bytes emitted so far, header included
+    Sha256 sha;                         // of exactly those bytes
+    unsigned long long stats_bytes, recon_bytes;
+};
+
+}  // namespace nblic
+
+struct nblic_amd_stream {
+    nblic_amd_ctx *c = nullptr;
+    int gid = -1;
+    int h = 0, w = 0, near = 0, effort = 1, k_step = 3, band_rows = 1, next_row = 0;
+    const uint8_t *d_img = nullptr; uint8_t *own_img = nullptr;        // the whole plane on the device
+    uint8_t *d_recon = nullptr;                                         // whole reconstruction (near > 0 or rows too wide for LDS)
+    double *d_stats = nullptr; size_t stats_bytes = 0;                  // [B | F], efforts 2 / 3
+    uint16_t *d_coded = nullptr; size_t coded_cap = 0;                  // one band's coded bins
+    uint16_t *h_coded = nullptr; size_t h_coded_cap = 0;                // the same, page-locked host memory
+    uint32_t lo = 0, hi = 0xFFFFFFFFu;
+    unsigned long long bytes_total = 0;
+    nblic::Sha256 sha;
+    bool finished = false, failed = false;
+    long bands = 0;
+    double model_ms = 0;
+};
+
+namespace nblic {
+
+static void stream_free(nblic_amd_stream *s) {
+    if (!s) return;
+    if (s->c && hipSetDevice(s->c->device) == hipSuccess) {
+        hipFree(s->own_img); hipFree(s->d_recon); hipFree(s->d_stats); hipFree(s->d_coded);
+        locked_free(s->h_coded);
+    }
+    if (s->c && s->gid >= 0) release_group(s->c, s->gid);
+    delete s;
+}
+
+static nblic_amd_stream *stream_open(nblic_amd_ctx *c, const unsigned char *img, bool on_device, int h, int w, int near, int effort, int band_rows) {
+    if (!c || !img || !size_ok(h, w, c->max_px) || hipSetDevice(c->device) != hipSuccess) return nullptr;
+    auto *s = new nblic_amd_stream;
+    s->c = c; s->h = h; s->w = w; s->near = iclip(near, 0, kMaxNear); s->effort = iclip(effort, 1, 3); s->k_step = k_step_for_near(s->near);
+    s->band_rows = band_rows > 0 ? (band_rows < h ? band_rows : h) : serial_rows_per_launch(h, w, s->effort, 0);
+    {   // a group of the context for as long as the stream lives: its first slot's band workspace, its stream, its pinned job records
+        std::unique_lock<std::mutex> l(c->fm);
+        c->fcv.wait(l, [c] { return !c->free_groups.empty(); });
+        s->gid = c->free_groups.front(); c->free_groups.pop_front();
+    }
+    Group &g = c->groups[size_t(s->gid)];
+    const size_t n = size_t(h) * size_t(w);
+    bool ok = true;
+    if (on_device) s->d_img = img;
+    else ok = hipMalloc((void **)&s->own_img, n) == hipSuccess && hipMemcpyAsync(s->own_img, img, n, hipMemcpyHostToDevice, g.stream) == hipSuccess && (s->d_img = s->own_img, true);
+    if (ok && (s->near > 0 || !serial_model_rows_fit(w))) ok = hipMalloc((void **)&s->d_recon, n) == hipSuccess;
+    s->stats_bytes = stats_doubles(s->effort, w) * sizeof(double);
+    if (ok && s->stats_bytes) ok = hipMalloc((void **)&s->d_stats, s->stats_bytes) == hipSuccess && hipMemsetAsync(s->d_stats, 0, s->stats_bytes, g.stream) == hipSuccess;   // NBLIC.c:789
+    Slot &sl = g.slots[0];
+    ok = ok && ensure_pixels(sl, size_t(s->band_rows) * size_t(w));
+    if (!ok) { fprintf(stderr, "[nblic_amd] stream: cannot set up the band workspace\n"); stream_free(s); return nullptr; }
+    return s;
+}
+
+// the job records of the band that starts at row i0
+static void stream_band_jobs(nblic_amd_stream *s, Group &g, int i0, int rows, uint32_t n_ev) {
+    Slot &sl = g.slots[0];
+    E1Job &J = g.h_jobs[0];
+    J = E1Job{};
+    J.b = sl.b; J.b.img = s->d_img + size_t(i0) * size_t(s->w); J.b.coded = s->d_coded;
+    J.h = rows; J.w = s->w; J.n = uint32_t(size_t(rows) * size_t(s->w)); J.pp = make_plan(J.n);
+    J.n_ev = n_ev; J.pe = make_plan(n_ev, kTouchSegments); J.dbg = 0;
+    J.near = s->near; J.k_step = s->k_step; J.ktab = level_shift_table(s->k_step);
+    SerialJob &Q = g.h_sjobs[0];
+    Q = SerialJob{};
+    Q.img = s->d_img; Q.recon = s->d_recon; Q.rec1 = sl.b.rec1; Q.pxs = sl.b.pxs; Q.stats = s->d_stats; Q.state = sl.d_state;
+    Q.h = s->h; Q.w = s->w; Q.near = s->near; Q.k_step = s->k_step; Q.effort = s->effort; Q.rows = rows; Q.out_row0 = i0;
+}
+
+// Runs bands until the image is finished or the budget is spent.  1 finished, 0 suspended between two bands, -1 error.
+static int stream_run(nblic_amd_stream *s, double budget_s, unsigned char *out, size_t cap, size_t *out_len) {
+    *out_len = 0;
+    if (!s || s->failed) return -1;
+    if (s->finished) return 1;
+    nblic_amd_ctx *c = s->c;
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    Group &g = c->groups[size_t(s->gid)];
+    Slot &sl = g.slots[0];
+    const auto t0 = std::chrono::steady_clock::now();
+    auto fail = [&](const char *what) { fprintf(stderr, "[nblic_amd] stream: %s\n", what); s->failed = true; hipStreamSynchronize(g.stream); return -1; };
+    uint8_t *p = out;
+    if (s->bytes_total == 0) {                                          // a fresh image: header, tables, state record
+        if (cap < size_t(kHeaderBytes) + 4) return fail("output buffer too small");
+        write_header(p, s->h, s->w, s->near, s->k_step, s->effort);
+        p += kHeaderBytes;
+        stream_band_jobs(s, g, 0, 1, 0);
+        if (hipMemcpyAsync(g.d_jobs, g.h_jobs, sizeof(E1Job), hipMemcpyHostToDevice, g.stream) != hipSuccess) return fail("upload");
+        e1_launch_init(g.d_jobs, 1, g.stream);
+        if (hipMemsetAsync(sl.d_state, 0, sizeof(SerialState), g.stream) != hipSuccess) return fail("state");
+    }
+    RangeScalar rc;
+    rc.begin(p, cap - size_t(p - out));
+    rc.lo = s->lo; rc.hi = s->hi;
+    while (s->next_row < s->h) {
+        const int i0 = s->next_row, rows = std::min(s->band_rows, s->h - i0);
+        stream_band_jobs(s, g, i0, rows, 0);
+        hipEvent_t e0 = g.tm.ev[0], e1 = g.tm.ev[1];
+        if (hipMemcpyAsync(g.d_jobs, g.h_jobs, sizeof(E1Job), hipMemcpyHostToDevice, g.stream) != hipSuccess ||
+            hipMemcpyAsync(g.d_sjobs, g.h_sjobs, sizeof(SerialJob), hipMemcpyHostToDevice, g.stream) != hipSuccess) return fail("upload");
+        hipEventRecord(e0, g.stream);
+        if (!serial_model_launch(g.d_sjobs, g.h_sjobs, 1, g.stream)) return fail("model launch");
+        hipEventRecord(e1, g.stream);
+        e1_launch_front_pre(g.d_jobs, g.h_jobs, 1, g.stream);
+        if (hipMemcpyAsync(g.h_totals, g.d_totals, kTotalsStride * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+            hipStreamSynchronize(g.stream) != hipSuccess) return fail("front half");
+        { float ms = 0.f; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) s->model_ms += ms; }
+        const uint32_t n_ev = g.h_totals[2];
+        if (n_ev >= 0x7FFFFFFFu || !ensure_events(sl, n_ev)) return fail("bin count");
+        if (size_t(n_ev) + 8 > s->coded_cap) {
+            hipFree(s->d_coded); s->d_coded = nullptr; locked_free(s->h_coded); s->h_coded = nullptr;
+            s->coded_cap = size_t(n_ev) + size_t(n_ev) / 4 + 4096;
+            if (hipMalloc((void **)&s->d_coded, s->coded_cap * sizeof(uint16_t)) != hipSuccess) return fail("coded bins");
+            s->h_coded = locked_alloc(s->coded_cap);
+            if (!s->h_coded) return fail("pinned bins");
+        }
+        stream_band_jobs(s, g, i0, rows, n_ev);
+        if (hipMemcpyAsync(g.d_jobs, g.h_jobs, sizeof(E1Job), hipMemcpyHostToDevice, g.stream) != hipSuccess) return fail("upload");
+        e1_launch_back(g.d_jobs, g.h_jobs, 1, g.stream, nullptr, true);
+        if (n_ev && hipMemcpyAsync(s->h_coded, s->d_coded, size_t(n_ev) * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream) != hipSuccess) return fail("bins to the host");
+        if (hipStreamSynchronize(g.stream) != hipSuccess) return fail("back half");
+        rc.feed(s->h_coded, n_ev);
+        if (rc.overflow) return fail("output buffer too small");
+        s->next_row = i0 + rows; s->bands++;
+        { std::lock_guard<std::mutex> l(c->stat_m); c->serial_launch_count++; }
+        if (budget_s > 0 && s->next_row < s->h && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= budget_s) break;
+    }
+    s->lo = rc.lo; s->hi = rc.hi;
+    size_t n = size_t(rc.p - out);
+    if (s->next_row >= s->h) {
+        const size_t body = rc.finish();                                 // the four flush bytes (NBLIC.c:576-586)
+        if (body == SIZE_MAX) return fail("output buffer too small");
+        n = size_t(rc.p - out);
+        s->finished = true;
+    }
+    s->sha.update(out, n);
+    s->bytes_total += n;
+    *out_len = n;
+    return s->finished ? 1 : 0;
+}
+
+static size_t stream_checkpoint_bytes(const nblic_amd_stream *s) {
+    return sizeof(BandCheckpoint) + kModelStateBytes + s->stats_bytes / 2 + 512 * 60 * sizeof(int) + 4096 * 2 * sizeof(int) + (s->d_recon ? 2 * size_t(s->w) : 0);
+}
+
+static size_t stream_checkpoint(nblic_amd_stream *s, void *buf, size_t cap) {
+    const size_t need = stream_checkpoint_bytes(s);
+    if (!buf || cap < need) return need;
+    if (s->failed || hipSetDevice(s->c->device) != hipSuccess) return 0;
+    Group &g = s->c->groups[size_t(s->gid)];
+    Slot &sl = g.slots[0];
+    BandCheckpoint H{};
+    memcpy(H.magic, "NBLCKPT1", 8);
+    H.h = s->h; H.w = s->w; H.near = s->near; H.effort = s->effort; H.band_rows = s->band_rows; H.next_row = s->next_row;
+    H.lo = s->lo; H.hi = s->hi; H.bytes_total = s->bytes_total; H.sha = s->sha;
+    H.stats_bytes = s->stats_bytes / 2; H.recon_bytes = s->d_recon ? 2 * size_t(s->w) : 0;
+    uint8_t *p = static_cast<uint8_t *>(buf);
+    memcpy(p, &H, sizeof H); p += sizeof H;
+    bool ok = hipMemcpy(p, sl.d_state, kModelStateBytes, hipMemcpyDeviceToHost) == hipSuccess; p += kModelStateBytes;
+    if (H.stats_bytes) ok = ok && hipMemcpy(p, s->d_stats, H.stats_bytes, hipMemcpyDeviceToHost) == hipSuccess;       // the column statistics B; the row pre-pass F is recomputed
+    p += H.stats_bytes;
+    ok = ok && hipMemcpy(p, sl.b.map_state, 512 * 60 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess; p += 512 * 60 * sizeof(int);
+    ok = ok && hipMemcpy(p, sl.b.cnt_state, 4096 * 2 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess; p += 4096 * 2 * sizeof(int);
+    if (H.recon_bytes) {                                                  // the two rows above the next one (fewer at the top of the image: zeros)
+        memset(p, 0, H.recon_bytes);
+        const int r0 = s->next_row >= 2 ? s->next_row - 2 : 0, nr = s->next_row - r0;
+        if (nr > 0) ok = ok && hipMemcpy(p + size_t(2 - nr) * size_t(s->w), s->d_recon + size_t(r0) * size_t(s->w), size_t(nr) * size_t(s->w), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    return ok ? need : 0;
+}
+
+static nblic_amd_stream *stream_resume(nblic_amd_ctx *c, const unsigned char *img, bool on_device, const void *ck, size_t ck_len) {
+    if (!ck || ck_len < sizeof(BandCheckpoint)) return nullptr;
+    BandCheckpoint H;
+    memcpy(&H, ck, sizeof H);
+    if (memcmp(H.magic, "NBLCKPT1", 8) != 0) return nullptr;
+    nblic_amd_stream *s = stream_open(c, img, on_device, H.h, H.w, H.near, H.effort, H.band_rows);
+    if (!s) return nullptr;
+    if (ck_len != stream_checkpoint_bytes(s) || H.stats_bytes != s->stats_bytes / 2 || H.next_row < 0 || H.next_row > H.h) { stream_free(s); return nullptr; }
+    Group &g = c->groups[size_t(s->gid)];
+    Slot &sl = g.slots[0];
+    s->next_row = H.next_row; s->lo = H.lo; s->hi = H.hi; s->bytes_total = H.bytes_total; s->sha = H.sha;
+    s->finished = false;
+    const uint8_t *p = static_cast<const uint8_t *>(ck) + sizeof H;
+    bool ok = hipStreamSynchronize(g.stream) == hipSuccess;
+    ok = ok && hipMemcpy(sl.d_state, p, kModelStateBytes, hipMemcpyHostToDevice) == hipSuccess; p += kModelStateBytes;
+    if (H.stats_bytes) ok = ok && hipMemcpy(s->d_stats, p, H.stats_bytes, hipMemcpyHostToDevice) == hipSuccess;
+    p += H.stats_bytes;
+    ok = ok && hipMemcpy(sl.b.map_state, p, 512 * 60 * sizeof(int), hipMemcpyHostToDevice) == hipSuccess; p += 512 * 60 * sizeof(int);
+    ok = ok && hipMemcpy(sl.b.cnt_state, p, 4096 * 2 * sizeof(int), hipMemcpyHostToDevice) == hipSuccess; p += 4096 * 2 * sizeof(int);
+    if (H.recon_bytes && s->d_recon) {
+        const int r0 = s->next_row >= 2 ? s->next_row - 2 : 0, nr = s->next_row - r0;
+        if (nr > 0) ok = ok && hipMemcpy(s->d_recon + size_t(r0) * size_t(s->w), p + size_t(2 - nr) * size_t(s->w), size_t(nr) * size_t(s->w), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok || s->bytes_total == 0) { stream_free(s); return nullptr; }
+    return s;
 }
 
 // ---- default context behind the drop-in entry points ---------------------------------------
@@ -1742,6 +1969,34 @@ int nblic_amd_decode_batch(nblic_amd_ctx *c, int n_images, const unsigned char *
     for (int k = 0; k < n_images; k++) if (status[k] != 0) return -1;
     return 0;
 }
+
+nblic_amd_stream *nblic_amd_stream_begin(nblic_amd_ctx *c, const unsigned char *img, int img_on_device, int height, int width, int near, int effort, int band_rows) {
+    return stream_open(c, img, img_on_device != 0, height, width, near, effort, band_rows);
+}
+nblic_amd_stream *nblic_amd_stream_resume(nblic_amd_ctx *c, const unsigned char *img, int img_on_device, const void *checkpoint, size_t checkpoint_bytes) {
+    return stream_resume(c, img, img_on_device != 0, checkpoint, checkpoint_bytes);
+}
+int nblic_amd_stream_run(nblic_amd_stream *s, double budget_seconds, unsigned char *out, size_t out_cap, size_t *out_len) {
+    size_t n = 0;
+    const int rc = stream_run(s, budget_seconds, out, out_cap, &n);
+    if (out_len) *out_len = n;
+    return rc;
+}
+size_t nblic_amd_stream_checkpoint(nblic_amd_stream *s, void *buf, size_t cap) { return s ? stream_checkpoint(s, buf, cap) : 0; }
+int nblic_amd_stream_progress(nblic_amd_stream *s, int *rows_done, unsigned long long *bytes_total, unsigned char sha256[32], double *model_ms) {
+    if (!s) return -1;
+    if (rows_done) *rows_done = s->next_row;
+    if (bytes_total) *bytes_total = s->bytes_total;
+    if (sha256) s->sha.digest(sha256);
+    if (model_ms) *model_ms = s->model_ms;
+    return s->failed ? -1 : (s->finished ? 1 : 0);
+}
+int nblic_amd_stream_recon(nblic_amd_stream *s, unsigned char *recon) {
+    if (!s || !recon || !s->finished || hipSetDevice(s->c->device) != hipSuccess) return -1;
+    const size_t n = size_t(s->h) * size_t(s->w);
+    return hipMemcpy(recon, s->near > 0 ? s->d_recon : s->d_img, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;    // lossless: the input (NBLIC.c:876)
+}
+void nblic_amd_stream_end(nblic_amd_stream *s) { stream_free(s); }
 
 int nblic_amd_set_device_coder(nblic_amd_ctx *c, int n_packs, int min_outstanding) {
     if (!c || n_packs < 0 || n_packs > 64) return -1;

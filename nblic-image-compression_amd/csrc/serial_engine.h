@@ -64,6 +64,7 @@ struct SerialJob {
     SerialState *state;        // resumable state (above): kModelStateBytes / kDecodeStateBytes / kQDecodeStateBytes
     int h, w, near, k_step, effort;
     int rows;                  // rows per launch (>= 1)
+    int out_row0;              // encode: the row whose records sit at index 0 of rec1 / pxs (0, or the first row of the band they hold)
     // QNBLIC decode only
     const uint32_t *q_freq, *q_start; const uint8_t *q_slot;
 };

@@ -213,14 +213,15 @@ __device__ __forceinline__ double lsq_solve_split(double (&M)[(N + 2) / 2], cons
         col[k] = ck;
         // every lane prepares the reciprocal of ITS candidate while the pivot search runs: the winner's is fetched with
         // its value, and the reciprocal's dependent chain is off the step's critical path
-        const double rs_c = lsq::recip_short(ck);
+        const double raw_c = lsq::recip_raw(ck);
         // pivot: largest |entry| of column k among the rows at positions >= k, first position wins (NBLIC.c:121-127)
         const double key = row_max((live & (pos >= k)) ? fma(fabs(ck), 256.0, double((15 - pos) * 16 + row)) : -1.0);
         const int tag = int(fma(-256.0, floor(key * (1.0 / 256.0)), key));
         const int c = tag & 15, pc = 15 - (tag >> 4);
         const int src = row_base4 | (c << 2);
         const int s0 = (k + 1) >> 1;                                     // first slot with a column beyond k in either half
-        const double d = fetch_f64(ck, src), rs = fetch_f64(rs_c, src);
+        const double d = fetch_f64(ck, src);
+        const lsq::Recip rc = lsq::recip_of_raw(fetch_f64(raw_c, src));
         double prow[kS];                                                 // the pivot row's entries of this lane's columns: all requests go out together
 #pragma unroll
         for (int s = s0; s < kS; s++) prow[s] = fetch_f64(M[s], src);
@@ -234,7 +235,7 @@ __device__ __forceinline__ double lsq_solve_split(double (&M)[(N + 2) / 2], cons
         for (int s = s0; s < kS; s++) {
             // for even k half 0's slot s0 is the pivot column itself: it is done with (the reference never reads it again)
             const double ls = (!(k & 1) && s == s0) ? (half ? l : 0.0) : l;
-            M[s] -= lsq::muldiv_trunc(prow[s], ls, d, rs, g);
+            M[s] -= lsq::muldiv_trunc(prow[s], ls, d, rc, g);
             g.see_entry(M[s]);
         }
     }
@@ -242,18 +243,20 @@ __device__ __forceinline__ double lsq_solve_split(double (&M)[(N + 2) / 2], cons
     col[N - 1] = bcast_half<1>(M[(N - 1) >> 1]);
     diag = (live & (pos == N - 1)) ? col[N - 1] : diag;
     double rhs = bcast_half<0>(M[N >> 1]);                               // both halves finish the solve alike
-    const double rs_own = lsq::recip_short(diag);                        // every row's own reciprocal at once, fetched below
+    g.see_pivot(diag);                                                   // every divisor of the solve is some row's diagonal entry
+    const double raw_own = lsq::recip_raw(diag);                         // every row's own reciprocal at once, fetched below
 #pragma unroll
     for (int k = N - 1; k > 0; k--) {                                     // back substitution on the right-hand side (NBLIC.c:148-158)
         const int src = row_base4 | (at[k] << 2);
-        const double d = fetch_f64(diag, src), rsd = fetch_f64(rs_own, src), bk = fetch_f64(rhs, src);
+        const double d = fetch_f64(diag, src), bk = fetch_f64(rhs, src);
+        const lsq::Recip rcd = lsq::recip_of_raw(fetch_f64(raw_own, src));
         ok &= int(d != 0.0);
         const double l = (live & (pos < k)) ? col[k] : 0.0;
-        rhs -= lsq::muldiv_trunc(bk, l, d, rsd, g);
+        rhs -= lsq::muldiv_trunc(bk, l, d, rcd, g);
         g.see_entry(rhs);
     }
     const int v = vn8[live ? pos : 14];
-    const double t = lsq::term(live ? rhs : 0.0, v, diag, rs_own, g);     // NBLIC.c:233-236
+    const double t = lsq::term(live ? rhs : 0.0, v, diag, lsq::recip_of_raw(raw_own), g);     // NBLIC.c:233-236
     return double(kMid << lsq::kFb1) + row_sum(live ? t : 0.0);
 }
 
@@ -262,7 +265,7 @@ template <int N>
 struct LsqEntries {
     static constexpr int kM = 1 + N + N * N, kSlots = kM > 64 ? 2 : 1, kStride = kM > 64 ? 128 : 64;
     int ia[kSlots], ib[kSlots];              // vn8 indices whose product is the entry's sample (b: x' x vn, A: vn x vn)
-    double scale[kSlots], ab[kSlots], abm1[kSlots], abh[kSlots], rab[kSlots];
+    double scale[kSlots], abm1[kSlots], abh[kSlots], rab[kSlots];
     bool active[kSlots];
     __device__ void init(int lane) {
 #pragma unroll
@@ -275,10 +278,10 @@ struct LsqEntries {
             else { ia[s] = (kk - 1 - N) / N; ib[s] = (kk - 1 - N) - ia[s] * N; }
             scale[s] = kk <= N ? lsq::kScaleB : lsq::kScaleA;
             const int a = kk ? lsq::kDecayV : lsq::kDecayS;
-            ab[s] = double(a); abm1[s] = double(a - 1); abh[s] = double(a / 2); rab[s] = lsq::kShort / double(a);
+            abm1[s] = double(a - 1); abh[s] = double(a / 2); rab[s] = 1.0 / double(a);
         }
     }
-    __device__ __forceinline__ double decay(double v, int s) const { return lsq::div_trunc(fma(v, abm1[s], abh[s]), ab[s], rab[s]); }
+    __device__ __forceinline__ double decay(double v, int s) const { return trunc(lsq::half_toward(fma(v, abm1[s], abh[s])) * rab[s]); }   // lsq::decay with the lane's constants
 };
 
 // once per row: right-to-left accumulation of the column sums (NBLIC.c:186-204); a lane owns its entries
@@ -379,7 +382,7 @@ struct LsqWalk {
         const double e0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(E[0]), 0), __builtin_amdgcn_readlane(__double2loint(E[0]), 0));
         const double f0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Fj[0]), 0), __builtin_amdgcn_readlane(__double2loint(Fj[0]), 0));
         const double s_sum = (e0 + f0) + floor(s_curr * 1.5);
-        const double sw = lsq::sample_weight(s_sum), rs = lsq::recip_short(sw);
+        const double sw = lsq::sample_weight(s_sum), rs = lsq::recip_raw(sw);
 #pragma unroll
         for (int s = 0; s < T::kSlots; s++) {
             const int prod = int(S.vn8[en.ia[s]]) * int(S.vn8[en.ib[s]]);
@@ -479,7 +482,7 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
 
     for (int i = i0; i < i1; i++) {
         uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
-        const size_t row_at = size_t(i) * size_t(w);
+        const size_t row_at = size_t(i) * size_t(w), out_at = size_t(i - J.out_row0) * size_t(w);
         if (CACHED) {                                                    // the row's ORIGINAL pixels; each is replaced by its reconstruction once coded
             for (int c = lane; c < w; c += 64) r0[c] = img[row_at + c];
             wave_sync();
@@ -521,7 +524,7 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
             S.pxs_ring[j & 63] = uint16_t(px | (sign << 8));
             if ((j & 63) == 63 || j == w - 1) {                          // a lane per record: coalesced stores
                 const int base = j & ~63;
-                if (base + lane <= j) { rec1[row_at + base + lane] = S.rec_ring[lane]; pxs[row_at + base + lane] = S.pxs_ring[lane]; }
+                if (base + lane <= j) { rec1[out_at + base + lane] = S.rec_ring[lane]; pxs[out_at + base + lane] = S.pxs_ring[lane]; }
             }
             if constexpr (N > 0) {
                 S.q.vn8[15] = int8_t(xr - kMid);
@@ -869,9 +872,10 @@ __global__ void k_selftest_div(const i64 *a, const i64 *b, const i64 *d, int n, 
     lsq::Guard g;
     const double dd = double(d[t]);
     const i64 want = mulw(a[t], b[t]) / d[t];
-    const double got = lsq::muldiv_trunc(double(a[t]), double(b[t]), dd, lsq::recip_short(dd), g);
-    const double rel = fabs(lsq::recip_short(dd) / lsq::kShort * dd - 1.0);            // the device reciprocal: seed + two Newton steps
-    if (!(rel < 1.0e-15)) atomicAdd(bad, 1u);
+    const double got = lsq::muldiv_trunc(double(a[t]), double(b[t]), dd, lsq::recip_of(dd), g);
+    const double raw = lsq::recip_raw(dd);                                              // the device reciprocal: seed + two Newton steps
+    const double rel = fabs(fma(raw, dd, -1.0));                                         // |raw * d - 1| exactly rounded once
+    if (!(rel < 1.5e-15)) atomicAdd(bad, 1u);                                            // 2^-49 = 1.78e-15
     if (i64(got) != want) atomicAdd(bad, 1u);
     const i64 v = a[t] >> 4;
     if (i64(lsq::decay<5>(double(v))) != (v * 4 + 2) / 5 || i64(lsq::decay<3>(double(v))) != (v * 2 + 1) / 3) atomicAdd(bad, 1u);

@@ -65,7 +65,8 @@ bool solve_f64(int n, double M[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, lsq::
         const double d = M[c][k];
         diag[c] = d;
         if (d == 0.0) return false;
-        const double rd = lsq::recip_short(d);
+        const lsq::Recip rd = lsq::recip_of(d);
+        g.see_pivot(d);
         for (int r = 0; r < n; r++) {
             if (pos[r] <= k) continue;
             const double l = M[r][k];
@@ -80,7 +81,9 @@ bool solve_f64(int n, double M[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, lsq::
         const int c = at[k];
         const double d = diag[c];
         if (d == 0.0) return false;
-        const double rd = lsq::recip_short(d), bk = M[c][n];
+        const lsq::Recip rd = lsq::recip_of(d);
+        const double bk = M[c][n];
+        g.see_pivot(d);
         for (int r = 0; r < n; r++) {
             if (pos[r] >= k) continue;
             M[r][n] -= lsq::muldiv_trunc(bk, M[r][k], d, rd, g);
@@ -88,7 +91,7 @@ bool solve_f64(int n, double M[lsq::kMaxN][lsq::kMaxN + 1], const int *vn, lsq::
         }
     }
     double p = double(kMid << lsq::kFb1);
-    for (int r = 0; r < n; r++) p += lsq::term(M[r][n], vn[pos[r]], diag[r], g);
+    for (int r = 0; r < n; r++) { g.see_pivot(diag[r]); p += lsq::term(M[r][n], vn[pos[r]], diag[r], lsq::recip_of(diag[r]), g); }
     *px = p;
     return true;
 }
@@ -179,7 +182,7 @@ extern "C" long hh_model_encode(const uint8_t *img_in, uint8_t *recon, int h, in
                 const i64 xq = i64(xr) << lsq::kFb1;
                 const double s_curr = double(abs64(p1 - xq));
                 const double s_sum = (E[0] + Fj[0]) + floor(s_curr * double(lsq::kDecayS) / double(lsq::kDecayS - 1));
-                const double s = lsq::sample_weight(s_sum), rs = lsq::recip_short(s);
+                const double s = lsq::sample_weight(s_sum), rs = lsq::recip_raw(s);
                 const int xc = xr - kMid;
                 for (int k = 0; k < m; k++) {
                     double sample;

@@ -121,21 +121,65 @@ def test_dropin_decoder_at_the_very_end_of_a_mapping(gpu_ctx, pkg, oracle):
 
 
 def test_damaged_streams_fail_fast_and_never_fault(gpu_ctx, pkg, oracle):
-    """(advisor, round 2) A QNBLIC stream whose histogram tables do not parse must never reach the GPU, however long
-    it is; an NBLIC stream that claims 10^8 pixels at -e3 and holds twenty bytes must fail at once instead of walking
-    the whole image; a truncated stream stops at the row it runs dry in."""
+    """(advisor, round 2) A QNBLIC stream whose histogram tables do not parse (it ends inside them) must never reach
+    the GPU; four megabytes of nonsense behind a QNBLIC header parse as SOME tables and may decode to anything, but
+    must not fault; an NBLIC stream that claims 10^8 pixels at -e3 and holds twenty bytes must fail at once instead
+    of walking the whole image; a truncated stream stops at the row it runs dry in."""
     ctx = pkg.Context(device=0, n_slots=4, n_coders=2)
     try:
-        bad_q = bytearray(b"Q0.2") + bytes([1, 0, 1, 0]) + bytes([0xFF, 0xFE] * (2 << 20))      # 1 x 1, four megabytes of nonsense tables
-        big = bytearray(b"NBLIC0.3") + bytes([1, 0x27, 0x10, 0x27, 0x10, 0, 3, 3]) + bytes(4)    # 10000 x 10000, -e3, 20 bytes
+        short_q = b"Q0.2" + bytes([1, 0, 1, 0]) + bytes(200)                                    # ends inside the first histogram
+        long_q = b"Q0.2" + bytes([1, 0, 1, 0]) + bytes([0xFF, 0xFE] * (2 << 20))                # 1 x 1, four megabytes of nonsense
+        big = b"NBLIC0.3" + bytes([1, 0x27, 0x10, 0x27, 0x10, 0, 3, 3]) + bytes(4)              # 10000 x 10000, -e3, 20 bytes
         good = oracle.encode(inputs.syn1(200, 300, 9), 0, 2)[0]
         t0 = time.time()
-        res = ctx.decode_batch([bytes(bad_q), bytes(big), good[: len(good) // 2], good])
+        res = ctx.decode_batch([short_q, long_q, big, good[: len(good) // 2], good])
         assert time.time() - t0 < 60
-        assert res[0] is None and res[1] is None and res[2] is None
-        assert res[3] is not None and np.array_equal(res[3][0], inputs.syn1(200, 300, 9))
+        assert res[0] is None and res[2] is None and res[3] is None
+        assert res[1] is None or res[1][0].shape == (1, 1)
+        assert res[4] is not None and np.array_equal(res[4][0], inputs.syn1(200, 300, 9))
     finally:
         ctx.close()
-    # (the drop-in decoders cannot tell a truncated stream from one followed by readable memory -- neither can the
-    # reference; what they can refuse without a length is tested here)
-    assert pkg.qdecompress(bytes(bad_q)) is None
+    # (the drop-in decoders get no length: they cannot tell a truncated stream from one followed by readable memory, and
+    # neither can the reference; their own refusals -- magic, size -- are in test_gpu_parity.py)
+
+
+def test_band_stream_equals_one_piece_and_survives_checkpoints(gpu_ctx, pkg, oracle):
+    """An image worked through in row bands (nblic_amd_stream): the bytes are the reference's; suspended after EVERY
+    band, written down as a checkpoint, the encoder thrown away and a new one -- in a new context -- resumed from the
+    checkpoint, the pieces still concatenate to the reference's stream, the running SHA-256 that travels with the
+    checkpoint is the stream's, and the reconstruction is the reference's."""
+    cases = [(inputs.syn1(200, 300, 3), 2, 2, 37), (inputs.syn1(96, 700, 4), 0, 3, 16), (inputs.make("noise", 64, 64), 1, 1, 7),
+             (inputs.syn1(5, 52000, 6), 3, 2, 2), (inputs.syn1(33, 40, 8), 9, 1, 33)]
+    for img, near, effort, band in cases:
+        want, wrec, *_ = oracle.encode(img, near, effort)
+        ctx = pkg.Context(device=0, n_slots=2, n_coders=1)
+        try:
+            st = ctx.stream(img, near, effort, band_rows=band)
+            done, whole = st.run()
+            assert done and whole == want, (img.shape, near, effort)
+            assert st.progress()["sha256"] == hashlib.sha256(want).hexdigest()
+            assert np.array_equal(st.recon(), wrec)
+            st.close()
+        finally:
+            ctx.close()
+        pieces, ck, steps = [], None, 0
+        while True:
+            ctx = pkg.Context(device=0, n_slots=2, n_coders=1)
+            try:
+                st = ctx.stream(img, near, effort, band_rows=band, checkpoint=ck)
+                done, piece = st.run(1e-9)                               # the budget is spent after one band
+                pieces.append(piece)
+                steps += 1
+                if done:
+                    prog = st.progress()
+                    rec = st.recon()
+                    st.close()
+                    break
+                ck = st.checkpoint()
+                st.close()
+            finally:
+                ctx.close()
+        assert steps == (img.shape[0] + band - 1) // band
+        assert b"".join(pieces) == want, (img.shape, near, effort)
+        assert prog["sha256"] == hashlib.sha256(want).hexdigest() and prog["bytes_total"] == len(want)
+        assert np.array_equal(rec, wrec)
