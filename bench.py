@@ -29,26 +29,43 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy
 
 
-def cpu_baseline(frames, reps_budget_s=12.0):
+def cpu_baseline(frames, effort=1, reps_budget_s=12.0):
     """Single-thread CPU encode of the same frames: the compiled reference when oracle/_ref
-    travelled with the snapshot, else our CPU port.  Bounded sample (a few frames)."""
+    travelled with the snapshot, else our CPU port.  Bounded sample (a few frames).  The thread is PINNED to
+    one core of the rank's slice for the measurement (taskset) -- the last one, which no
+    coder thread is bound to -- and the line says which."""
     from oracle.oracle import Oracle, Reference
     if Reference.available():
-        enc, kind = Reference().encode, "reference"
+        r = Reference()
+        enc, kind = (r.encode if effort else (lambda im, n, e: (r.qencode(im),))), "reference"
     else:
         o = Oracle()
-        enc, kind = (lambda im, n, e: o.encode(im, n, e)), "port"
+        enc, kind = ((lambda im, n, e: o.encode(im, n, e)) if effort else (lambda im, n, e: (o.qencode(im),))), "port"
+    pinned, before = None, None
+    try:
+        before = os.sched_getaffinity(0)
+        pinned = max(before)
+        os.sched_setaffinity(0, {pinned})               # pid 0 = the calling thread only
+    except (AttributeError, OSError, ValueError):
+        pinned = None
     px, t_total, used, streams = 0, 0.0, 0, []
-    for f in frames:
-        t0 = time.perf_counter()
-        streams.append(enc(f, 0, 1)[0])
-        t_total += time.perf_counter() - t0
-        px += f.size
-        used += 1
-        if t_total > reps_budget_s:
-            break
-    return {"value": round(px / t_total / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": kind,
-            "sample": f"{used} of the batch's {frames[0].shape[0]}x{frames[0].shape[1]} SYN-1 frames, -n0 -e1, one thread"}, streams, enc
+    try:
+        for f in frames:
+            t0 = time.perf_counter()
+            streams.append(enc(f, 0, 1)[0])
+            t_total += time.perf_counter() - t0
+            px += f.size
+            used += 1
+            if t_total > reps_budget_s:
+                break
+    finally:
+        if before is not None:
+            try:
+                os.sched_setaffinity(0, before)
+            except OSError:
+                pass
+    return {"value": round(px / t_total / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": kind, "pinned_core": pinned,
+            "sample": f"{used} of the batch's {frames[0].shape[0]}x{frames[0].shape[1]} SYN-1 frames, -n0 -e{effort}, one thread pinned to one core"}, streams, enc
 
 
 def verify_frames(enc, make_frame, indices, got, workers):
@@ -110,27 +127,82 @@ def launch_ranks(n_gpus, backend):
     sys.exit(rc)
 
 
-def cpu_share(local_rank, gpus_per_node):
-    """The logical CPUs of this rank's 1/gpus_per_node slice of the host: whole physical cores (both SMT
-    siblings), consecutive core ids (cores 16r .. 16r+15 of a 128-core, 8-GPU box are on GPU r's socket).
-    At N = 1 the rank still takes only its eighth, so the single-GPU figure is what a rank of the 8-GPU
-    job gets.  Returns None when the topology cannot be read."""
+def parse_cpulist(text):
+    """'0-15,128-143' -> [0, ..., 15, 128, ..., 143]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out += list(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_local_cpulists(sysfs="/sys"):
+    """local_cpulist (the CPUs of the GPU's own NUMA node) of every AMD GPU, in render-node order -- the order the HIP
+    runtime enumerates them in; HIP_VISIBLE_DEVICES (a list of ordinals) is applied.  [] when sysfs does not say."""
+    import glob
+    nodes = []
+    for d in glob.glob(os.path.join(sysfs, "class", "drm", "renderD*")):
+        try:
+            with open(os.path.join(d, "device", "vendor")) as f:
+                if int(f.read().strip(), 16) != 0x1002:
+                    continue
+            with open(os.path.join(d, "device", "local_cpulist")) as f:
+                cpus = parse_cpulist(f.read())
+            numa = -1
+            try:
+                with open(os.path.join(d, "device", "numa_node")) as f:
+                    numa = int(f.read().strip())
+            except (OSError, ValueError):
+                pass
+            nodes.append((int(os.path.basename(d)[7:]), numa, cpus))
+        except (OSError, ValueError):
+            continue
+    nodes.sort()
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if vis:
+        try:
+            nodes = [nodes[int(v)] for v in vis.split(",") if v.strip() != ""]
+        except (ValueError, IndexError):
+            pass
+    return [(numa, cpus) for _, numa, cpus in nodes]
+
+
+def cpu_share(local_rank, gpus_per_node, sysfs="/sys", avail=None):
+    """The logical CPUs this rank confines itself to: whole physical cores (both SMT siblings) of ITS GPU's NUMA node
+    (sysfs local_cpulist of the GPU's PCI device), that node's cores split evenly, in core order, between the GPUs that
+    hang off it.  At N = 1 the rank still takes only the share one of `gpus_per_node` GPUs gets, so the single-GPU figure
+    is what a rank of the 8-GPU job has.  Where sysfs says nothing about the GPUs (containers, this build box) the host's
+    cores are split evenly by rank as before.  Returns (cpus, how) or (None, why)."""
     try:
-        avail = sorted(os.sched_getaffinity(0))
+        avail = sorted(os.sched_getaffinity(0)) if avail is None else sorted(avail)
         cores = {}
         for c in avail:
-            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
-                sib = f.read().strip()
-            first = int(sib.replace("-", ",").split(",")[0])
+            with open(os.path.join(sysfs, "devices", "system", "cpu", f"cpu{c}", "topology", "thread_siblings_list")) as f:
+                first = parse_cpulist(f.read())[0]
             cores.setdefault(first, []).append(c)
-        ordered = [cores[k] for k in sorted(cores)]
-        per = len(ordered) // gpus_per_node
-        if per < 1:
-            return None
-        mine = ordered[(local_rank % gpus_per_node) * per:(local_rank % gpus_per_node + 1) * per]
-        return sorted(c for core in mine for c in core)
-    except (OSError, ValueError, AttributeError):
-        return None
+    except (OSError, ValueError, AttributeError, IndexError):
+        return None, "cpu topology unreadable"
+    gpus = gpu_local_cpulists(sysfs)
+    slot = local_rank % max(1, gpus_per_node)
+    if len(gpus) > slot and gpus[slot][1]:
+        numa, local = gpus[slot]
+        local = set(local)
+        mine = [k for k in sorted(cores) if k in local]                       # physical cores of the GPU's node that we may use
+        peers = [i for i, (nn, cc) in enumerate(gpus[:max(gpus_per_node, len(gpus))]) if set(cc) == local]
+        share_of = max(len(peers), gpus_per_node * len(mine) // max(1, len(cores)))   # a lone visible GPU still leaves room for the node's other GPUs
+        idx = peers.index(slot) if slot in peers else 0
+        per = len(mine) // max(1, share_of)
+        if per >= 1:
+            part = mine[idx * per:(idx + 1) * per]
+            return sorted(c for k in part for c in cores[k]), f"numa node {numa} of GPU {slot}: cores {part[0]}..{part[-1]} ({idx + 1} of {share_of} on that node)"
+    ordered = [cores[k] for k in sorted(cores)]
+    per = len(ordered) // max(1, gpus_per_node)
+    if per < 1:
+        return None, "fewer cores than GPUs"
+    mine = ordered[slot * per:(slot + 1) * per]
+    return sorted(c for core in mine for c in core), f"even split by rank (sysfs names no NUMA node for GPU {slot})"
 
 
 def host_description():
@@ -150,7 +222,14 @@ def host_description():
     toggles = {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "NBLIC_AMD_HOSTMALLOC", "NBLIC_AMD_CHUNK_BINS", "NBLIC_AMD_DBG",
                                           "NBLIC_AMD_NO_SIMD", "NBLIC_AMD_DEVICE", "NBLIC_BENCH_DEVICE", "NBLIC_AMD_COPY_STREAMS",
                                           "NBLIC_BENCH_NO_STAGE_TIMING", "NBLIC_BENCH_SYSTEM_HIP", "DEBUG_CLR_LIMIT_BLIT_WG", "HSA_CU_MASK") if k in os.environ}
-    return {"cpu_model": model, "cpus_used_by_this_rank": cpus, "cpus_total": os.cpu_count(), "env": toggles}
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:           # "max 100000" or "<quota us> <period us>": CPUs' worth of time the cgroup may use
+            q, per = f.read().split()[:2]
+            quota = "unlimited" if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    return {"cpu_model": model, "cpus_used_by_this_rank": cpus, "cpus_total": os.cpu_count(), "cgroup_cpu_quota_cpus": quota, "env": toggles}
 
 
 def main():
@@ -181,7 +260,11 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 path be rehearsed with every rank on one GPU")
     ap.add_argument("--node-gpus", type=int, default=8, help="GPUs the host is shared between: a rank confines itself (threads and all) to 1/NODE_GPUS of the host's cores, both SMT siblings of each; 0 = no confinement")
     ap.add_argument("--launch-check", action="store_true", help="no GPU work: every rank joins a gloo group, rank 0 prints how many ranks it saw (tests the --gpus N launcher on a CPU-only box)")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed extra measurements (single frame, 8-frame batch, host inputs)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the extra measurements (single frame, 8-frame batch, the H2D-inclusive leg, the all-stage timing passes)")
+    ap.add_argument("--effort", type=int, choices=(0, 1), default=1, help="1: the graded -n0 -e1 path (BASELINE config 2); 0: QNBLIC (config 1's mode) on the same frames, one synchronous batch call per step")
+    ap.add_argument("--h2d-steps", type=int, default=10, help="timed steps of the H2D-inclusive leg (SURVEY 8(d): >= 10 after >= 3 warm-ups); 0 skips it")
+    ap.add_argument("--h2d-warmup", type=int, default=3)
+    ap.add_argument("--pinned-budget-gb", type=float, default=24.0, help="page-locked host memory one rank may hold (output slabs + coder rings); the coder threads' chunk is halved until the total fits, so eight ranks stay under 8 x this")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -191,10 +274,12 @@ def main():
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a mislabelled run", file=sys.stderr)
         sys.exit(2)
 
-    share = None
-    if args.node_gpus > 0 and not args.launch_check:
-        share = cpu_share(int(os.environ.get("LOCAL_RANK", "0")), max(args.node_gpus, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-        if share:
+    share, share_how = None, "no confinement"
+    if args.node_gpus > 0:
+        fake_cpus = os.environ.get("NBLIC_BENCH_ASSUME_CPUS")             # tests: a topology that is not this machine's (with NBLIC_BENCH_SYSFS)
+        share, share_how = cpu_share(int(os.environ.get("LOCAL_RANK", "0")), max(args.node_gpus, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))),
+                                     os.environ.get("NBLIC_BENCH_SYSFS", "/sys"), range(int(fake_cpus)) if fake_cpus else None)
+        if share and not args.launch_check and not fake_cpus:
             os.sched_setaffinity(0, share)              # before torch / HIP start their threads: they inherit it
 
     if os.environ.get("NBLIC_BENCH_SYSTEM_HIP"):            # experiment: /opt/rocm's HIP + HSA runtimes instead of the ones bundled in the torch wheel
@@ -209,16 +294,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.launch_check:
-        seen = 1
+        seen, slices = 1, [{"rank": rank, "cpus": share, "how": share_how}]
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")
             t = torch.tensor([1], dtype=torch.int64)
             dist.all_reduce(t)
             seen = int(t.item())
+            every = [None] * world
+            dist.all_gather_object(every, slices[0])
+            slices = every
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "local_rank": local_rank}), flush=True)
+            line = {"launch_check": True, "n_gpus": world, "ranks_seen": seen, "local_rank": local_rank}
+            if os.environ.get("NBLIC_BENCH_SYSFS") or os.environ.get("NBLIC_BENCH_SHOW_SLICES"):
+                line["cpu_slices"] = slices
+            print(json.dumps(line), flush=True)
         return
     gpu = int(os.environ.get("NBLIC_BENCH_DEVICE", local_rank))       # rehearsal: all ranks on one GPU
     if world > 1:
@@ -259,6 +350,19 @@ def main():
     if not args.overlap_steps:
         in_flight = 1
     host_buffers = args.host_buffers or (min(B + 16, slots + 24 * coders + 32) + 64 * dev_packs)   # groups in flight + every thread's sixteen + a queue (+ the device coder's packs)
+    # page-locked host memory of this rank: the output slabs (a set per step in flight) and every coder thread's ring
+    # (3 slots x 24 lanes x chunk bins x 13/8 bytes).  Eight ranks share one host: the chunk is halved until the rank is
+    # under its budget (the library reads NBLIC_AMD_CHUNK_BINS when the context is created)
+    cap = H * W + H * W // 4 + 4096 if args.host_inputs else H * W * 3 // 4 + 4096   # SYN-1 codes to 0.53 B/px
+    chunk_bins = int(os.environ.get("NBLIC_AMD_CHUNK_BINS", 1 << 22))
+    slab_bytes = in_flight * B * cap
+    ring_bytes = lambda ch: coders * 3 * 24 * ch * 13 // 8
+    while slab_bytes + ring_bytes(chunk_bins) > args.pinned_budget_gb * 1e9 and chunk_bins > (1 << 18):
+        chunk_bins //= 2
+    if chunk_bins != (1 << 22):
+        os.environ["NBLIC_AMD_CHUNK_BINS"] = str(chunk_bins)
+    pinned = {"output_slabs_GB": round(slab_bytes / 1e9, 2), "coder_rings_GB": round(ring_bytes(chunk_bins) / 1e9, 2), "budget_GB": args.pinned_budget_gb,
+              "coder_chunk_bins": chunk_bins}
     ctx = pkg.Context(device=gpu, n_slots=slots, n_coders=coders, n_groups=max(1, min(args.groups, slots)),
                       n_host_buffers=host_buffers)
     # HIP events around the two kernels the line reports against a roof (k_touch_scatter, the dominant one by time per
@@ -269,7 +373,6 @@ def main():
         ctx.set_device_coder(dev_packs, args.device_min_outstanding if args.device_min_outstanding >= 0 else int(2.8 * B))
     # streams land in one pinned slab (a slot per frame: worst case seen is 1.0025 B/px) so that the
     # multi-GPU gather can stage them to HBM with plain async copies
-    cap = H * W + H * W // 4 + 4096 if args.host_inputs else H * W * 3 // 4 + 4096   # SYN-1 codes to 0.53 B/px
     slab = torch.empty((B, cap), dtype=torch.uint8, pin_memory=True)
     outs = [slab[k].numpy() for k in range(B)]
     slabs, out_sets = [slab], [outs]
@@ -287,6 +390,8 @@ def main():
     last = {}
 
     all_lens = []
+    step_done = []                                        # when each step of the current run() was complete (streams in host memory, exchanged)
+    outs16 = [[o[: o.size & ~1].view(np.uint16) for o in oset] for oset in out_sets]     # effort 0 writes 16-bit words (QNBLIC.h:14)
 
     def exchange(lens, which):
         last["lens"], last["outs"] = lens, out_sets[which]
@@ -304,20 +409,41 @@ def main():
                 last["gathered_first"] = k0
             torch.cuda.current_stream().synchronize()   # the slab rows are free for a later step's coders only now
 
-    def run(n_steps):
+    def run(n_steps, src=None, on_device=None):
+        src = ptrs if src is None else src
+        on_device = (not args.host_inputs) if on_device is None else on_device
+        del step_done[:]
+        if args.effort == 0:                             # QNBLIC: one synchronous batch call per step (lengths come back in words)
+            for _ in range(n_steps):
+                _, words = ctx.qencode_ptrs(src, shapes, on_device, outs16[0])
+                exchange(words * 2, 0)
+                step_done.append(time.perf_counter())
+            return
         if not args.overlap_steps:
             for _ in range(n_steps):
-                _, lens = ctx.encode_ptrs(ptrs, shapes, not args.host_inputs, outs)
+                _, lens = ctx.encode_ptrs(src, shapes, on_device, outs)
                 exchange(lens, 0)
+                step_done.append(time.perf_counter())
             return
         pending = []                                    # up to in_flight steps are submitted before the oldest is collected (and exchanged)
         for i in range(n_steps):
             if len(pending) == in_flight:
                 t, which = pending.pop(0)
                 exchange(ctx.encode_end(t)[1], which)
-            pending.append((ctx.encode_begin(ptrs, shapes, not args.host_inputs, out_sets[i % in_flight]), i % in_flight))
+                step_done.append(time.perf_counter())
+            pending.append((ctx.encode_begin(src, shapes, on_device, out_sets[i % in_flight]), i % in_flight))
         for t, which in pending:
             exchange(ctx.encode_end(t)[1], which)
+            step_done.append(time.perf_counter())
+
+    def step_stats(t_start):
+        """median / min of the intervals between the completions of consecutive steps (the first one is measured from
+        the start of the region and, with steps in flight, contains the pipeline's fill)"""
+        marks = [t_start] + list(step_done)
+        iv = sorted(b - a for a, b in zip(marks[:-1], marks[1:]))
+        if not iv:
+            return None, None
+        return round(iv[len(iv) // 2] * 1e3 if len(iv) % 2 else (iv[len(iv) // 2 - 1] + iv[len(iv) // 2]) * 0.5e3, 3), round(iv[0] * 1e3, 3)
 
     def fence():
         torch.cuda.synchronize()
@@ -332,10 +458,14 @@ def main():
     run(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    step_median_ms, step_min_ms = step_stats(t0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    timed_stage = ctx.stage_times()                   # the two stages timed INSIDE the region (summed over its group launches)
+    timed_launches = max(1, ctx.last_launches())
+    timed_bins, timed_coder_s = ctx.last_stats()
 
     # ---- reporting (outside the timed region) ------------------------------------------------
     if os.environ.get("NBLIC_BENCH_THREAD_CPU"):          # who used the rank's CPU share: CPU seconds per thread name since process start
@@ -360,17 +490,13 @@ def main():
         except OSError:
             pass
     lens = last["lens"]
-    stage = ctx.stage_times()                         # summed over the group launches of the last step
-    launches = max(1, ctx.last_launches())            # each kernel is launched once per group of images
-    bins, coder_s = ctx.last_stats()
+    timed_lens = np.array(lens, copy=True)
+    timed_outs, timed_all_lens = last["outs"], list(all_lens)
+    bins, coder_s = timed_bins, timed_coder_s
     dev_stats = ctx.device_coder_stats() if dev_packs else None
-    per_launch = {k: v / launches for k, v in stage.items() if k != "host_gap" and (v > 0 or args.stage_timing == "all")}
-    if not per_launch:
-        per_launch = {"k_touch_scatter": 0.0}
-    dom = max(per_launch, key=per_launch.get)
-    imgs_per_launch = B * (args.steps if args.overlap_steps else 1) / launches   # the library's timers run over all overlapped steps
-    alg_bytes = (H * W + float(np.mean(lens))) * imgs_per_launch   # 1 B/px read + L/N B/px written
-    achieved = alg_bytes / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] > 0 else 0.0
+    steps_counted = args.steps if (args.overlap_steps and args.effort == 1) else 1      # the library's counters run over all overlapped steps
+    imgs_per_launch = B * steps_counted / timed_launches
+    timed_per_launch = {k: v / timed_launches for k, v in timed_stage.items() if k != "host_gap" and v > 0}
 
     gathered_ok = None
     if world > 1 and rank == 0:
@@ -379,71 +505,29 @@ def main():
         gathered_ok = (len(payloads) == world and all(int(l.sum()) == p.numel() for p, l in zip(payloads, lens_all)) and
                        hashlib.sha256(payloads[0][: int(lens_all[0][0])].cpu().numpy().tobytes()).hexdigest() ==
                        hashlib.sha256(last["outs"][k0][: int(lens[k0])].tobytes()).hexdigest())
-    # ---- untimed extra legs: one frame alone, the 8-frame batch north_star names, host inputs --------
-    extra = {}
-    if not args.no_extra_legs:
-        def timed_call(fn):
-            fence()
-            t0 = time.perf_counter()
-            fn()
-            fence()
-            d = time.perf_counter() - t0
-            if world > 1:
-                tt = torch.tensor([d], dtype=torch.float64, device=comm_dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                d = float(tt.item())
-            return d
-        one = max(1, 8 // world)                                     # 8 frames over the whole job: 8 / N per GPU
-        d8 = timed_call(lambda: ctx.encode_ptrs(ptrs[:one], shapes[:one], not args.host_inputs, outs[:one]))
-        extra["batch8_Mpixel_per_s"] = round(one * world * H * W / d8 / 1e6, 2)
-        extra["batch8_frames_per_gpu"] = one
-        if world == 1:
-            d1 = min(timed_call(lambda: ctx.encode_ptrs(ptrs[:1], shapes[:1], not args.host_inputs, outs[:1])) for _ in range(3))
-            extra["single_frame_ms"] = round(d1 * 1e3, 2)
-            if not args.host_inputs:                                 # SURVEY 8(d)'s quantity: every frame uploaded over PCIe inside the region
-                # the same B frames in PINNED host memory (SURVEY allows it), two steps back to back like the headline
-                hslab = torch.empty((B, H * W), dtype=torch.uint8, pin_memory=True)
-                hrows = [hslab[k].numpy() for k in range(B)]
-                with ThreadPoolExecutor(max_workers=max(1, min(16, cpus))) as ex:
-                    list(ex.map(lambda k: np.copyto(hrows[k], pkg.syn1(H, W, seed=rank * B + k + 1).reshape(-1)), range(B)))
-                hptrs = [r.ctypes.data for r in hrows]
 
-                def two_steps():
-                    t1 = ctx.encode_begin(hptrs, shapes, False, out_sets[0])
-                    t2 = ctx.encode_begin(hptrs, shapes, False, out_sets[1 % len(out_sets)]) if len(out_sets) > 1 else None
-                    ctx.encode_end(t1)
-                    if t2 is not None:
-                        ctx.encode_end(t2)
-                n_steps_h = 2 if len(out_sets) > 1 else 1
-                dh = timed_call(two_steps)
-                extra["pcie_inclusive_Mpixel_per_s"] = round(n_steps_h * B * H * W / dh / 1e6, 2)
-                extra["pcie_inclusive_frames"] = n_steps_h * B
-                extra["pcie_inclusive_note"] = "frames in pinned host memory, uploaded inside the timed region; includes the pipeline's fill and drain once"
-                del hslab, hrows
-
-    # ---- correctness of what was timed (outside the timed region) ------------------------------------
+    # ---- correctness of what was timed (outside the timed region; before the extra legs reuse the buffers) --------
     bit_exact, checks = None, {}
     if rank == 0:
         try:
             with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
-                m = json.load(f)["large"].get(f"syn1s1_{H}x{W}_n0_e1")
+                m = json.load(f)["large"].get(f"syn1s1_{H}x{W}_n0_e1" if args.effort else f"syn1s1_{H}x{W}_q0")
             if m:
                 s0 = last["outs"][0][: int(lens[0])].tobytes()
                 checks["frame0_golden_sha"] = (len(s0) == m["len"] and hashlib.sha256(s0).hexdigest() == m["sha256"])
         except OSError:
             pass
         checks["every_step_same_lengths"] = all(np.array_equal(l, all_lens[0]) for l in all_lens) and len(all_lens) == args.steps
-        if args.overlap_steps and args.steps >= in_flight and in_flight >= 2 and args.warmup + args.steps >= in_flight:   # the last steps' slabs, byte for byte
+        if args.effort == 1 and args.overlap_steps and args.steps >= in_flight and in_flight >= 2 and args.warmup + args.steps >= in_flight:   # the last steps' slabs, byte for byte
             la = torch.from_numpy(np.asarray(lens)).clamp(max=cap)
             same = True
             for k in range(B):
                 n = int(la[k])
                 same = same and all(bool(torch.equal(slabs[0][k, :n], sl[k, :n])) for sl in slabs[1:])
             checks[f"last_{in_flight}_steps_identical"] = same
-
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, ref_streams, enc = cpu_baseline(frames)
+        cpu, ref_streams, enc = cpu_baseline(frames, args.effort)
         ok = [ref_streams[k] == last["outs"][k][: int(lens[k])].tobytes() for k in range(len(ref_streams))]
         spread = [k for k in sorted({(B * j) // 16 + (j % 16) for j in range(1, 16)}) if len(ref_streams) <= k < B]   # other packs, other lanes
         ok += verify_frames(enc, lambda k: pkg.syn1(H, W, seed=rank * B + k + 1), spread,
@@ -454,40 +538,130 @@ def main():
     if rank == 0:
         bit_exact = all(v for k, v in checks.items() if isinstance(v, bool))
 
+    # ---- extra legs (outside the headline's region): the H2D-inclusive rate under the same protocol, every stage timed
+    # under load and alone, one frame alone, the 8-frame batch north_star names ----------------------------------------
+    extra = {}
+    all_per_launch, alone_per_launch = {}, {}
+
+    def timed_call(fn):
+        fence()
+        t0 = time.perf_counter()
+        fn()
+        fence()
+        d = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([d], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return d
+    if not args.no_extra_legs and args.effort == 1:
+        # every one of the 31 stages timed in THIS run: two overlapped steps under the same six-group concurrency as the
+        # headline (thirty-two events per group launch cost ~2 %, which is why the timed region carries only two stages) ...
+        ctx.enable_timing(1)
+        run(min(2, max(1, args.steps)))
+        fence()
+        st, ln = ctx.stage_times(), max(1, ctx.last_launches())
+        all_per_launch = {k: v / ln for k, v in st.items() if k != "host_gap"}
+        # ... and one group of frames ALONE on the GPU (nothing else in flight): what each kernel needs by itself
+        n_alone = max(1, min(B, slots // max(1, min(args.groups, slots))))
+        ctx.encode_ptrs(ptrs[:n_alone], shapes[:n_alone], not args.host_inputs, outs[:n_alone])
+        fence()
+        st, ln = ctx.stage_times(), max(1, ctx.last_launches())
+        alone_per_launch = {k: v / ln for k, v in st.items() if k != "host_gap"}
+        extra["frames_per_launch_alone"] = n_alone / ln
+        ctx.enable_timing(0)
+    if not args.no_extra_legs:
+        one = max(1, 8 // world)                                     # 8 frames over the whole job: 8 / N per GPU
+        enc_some = (lambda k: ctx.qencode_ptrs(ptrs[:k], shapes[:k], not args.host_inputs, outs16[0][:k])) if args.effort == 0 else \
+                   (lambda k: ctx.encode_ptrs(ptrs[:k], shapes[:k], not args.host_inputs, outs[:k]))
+        d8 = sorted(timed_call(lambda: enc_some(one)) for _ in range(5))
+        extra["batch8_Mpixel_per_s"] = round(one * world * H * W / d8[len(d8) // 2] / 1e6, 2)
+        extra["batch8_ms"] = {"median": round(d8[len(d8) // 2] * 1e3, 2), "min": round(d8[0] * 1e3, 2), "repetitions": len(d8)}
+        extra["batch8_frames_per_gpu"] = one
+        if world == 1:
+            d1 = sorted(timed_call(lambda: enc_some(1)) for _ in range(13))[:-3]     # 13 repetitions, the three slowest (warm-up) dropped
+            extra["single_frame_ms"] = round(d1[len(d1) // 2] * 1e3, 2)
+            extra["single_frame"] = {"median_ms": round(d1[len(d1) // 2] * 1e3, 2), "min_ms": round(d1[0] * 1e3, 2), "repetitions": len(d1)}
+    if not args.no_extra_legs and world == 1 and not args.host_inputs and args.h2d_steps > 0 and args.effort == 1:
+        # SURVEY 8(d)'s quantity: input in (pinned) host memory, every frame uploaded over PCIe INSIDE the region, same
+        # protocol as the headline: warm-up steps, then K timed steps submitted back to back, barrier to barrier
+        hslab = torch.empty((B, H * W), dtype=torch.uint8, pin_memory=True)
+        hrows = [hslab[k].numpy() for k in range(B)]
+        with ThreadPoolExecutor(max_workers=max(1, min(16, cpus))) as ex:
+            list(ex.map(lambda k: np.copyto(hrows[k], pkg.syn1(H, W, seed=rank * B + k + 1).reshape(-1)), range(B)))
+        hptrs = [r.ctypes.data for r in hrows]
+        run(args.h2d_warmup, hptrs, False)
+        fence()
+        th0 = time.perf_counter()
+        run(args.h2d_steps, hptrs, False)
+        fence()
+        dh = time.perf_counter() - th0
+        h_med, h_min = step_stats(th0)
+        same = all(np.array_equal(l, timed_lens) for l in all_lens[-args.h2d_steps:])
+        extra["value_h2d_inclusive"] = {"value": round(args.h2d_steps * B * H * W / dh / 1e6, 2), "unit": "Mpixel/s", "steps": args.h2d_steps, "warmup": args.h2d_warmup,
+                                        "ms_per_step": round(dh / args.h2d_steps * 1e3, 3), "ms_per_step_median": h_med, "ms_per_step_min": h_min,
+                                        "same_streams_as_headline": bool(same), "pinned_input_GB": round(B * H * W / 1e9, 2),
+                                        "note": "frames in pinned host memory, uploaded inside the timed region (SURVEY 8(d)'s metric); same submission pattern as `value`"}
+        extra["pcie_inclusive_Mpixel_per_s"] = extra["value_h2d_inclusive"]["value"]
+        if not same:
+            bit_exact = False
+        del hslab, hrows
+    lens = timed_lens
+
     if rank == 0:
         total_px = float(H) * W * B * world * args.steps
         value = total_px / dt / 1e6
-        steps_counted = args.steps if args.overlap_steps else 1      # the library's counters run over all overlapped steps
+        # the dominant kernel by time per launch, chosen from THIS run's own timers: the all-stage pass when it ran (31
+        # stages under the same concurrency as the headline), else the stages timed inside the region
+        pool = {k: v for k, v in (all_per_launch or timed_per_launch).items() if v > 0} or {"k_touch_scatter": 0.0}
+        dom = max(pool, key=pool.get)
+        in_region = dom in timed_per_launch
+        launch_ms = timed_per_launch[dom] if in_region else pool[dom]
+        alg_bytes = (H * W + float(np.mean(lens))) * imgs_per_launch   # 1 B/px read + L/N B/px written
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        k_pred_ms = timed_per_launch.get("k_predict") or all_per_launch.get("k_predict") or 0.0
+        mode = "-n0 -e1" if args.effort else "-n0 -e0 (QNBLIC)"
         line = {
-            "metric": "Mpixel/s encode (bit-exact) 4096x4096 gray -e1 lossless",
+            "metric": "Mpixel/s encode (bit-exact) 4096x4096 gray -e1 lossless" if args.effort else "Mpixel/s encode (bit-exact) gray -e0 lossless (QNBLIC)",
             "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": step_median_ms, "ms_per_step_min": step_min_ms,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{B} x {H}x{W} SYN-1 gray frames per GPU per step, -n0 -e1, inputs resident in HBM" + (f", steps submitted back to back ({in_flight} in flight)" if args.overlap_steps else "")
-                       if not args.host_inputs else f"{B} x {H}x{W} SYN-1 frames per GPU per step, -n0 -e1, host inputs (PCIe-inclusive)",
-                       "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "coded_bin_buffers_in_hbm": host_buffers, "steps_overlapped": bool(args.overlap_steps), "steps_in_flight": in_flight,
+            "config": {"workload": f"{B} x {H}x{W} SYN-1 gray frames per GPU per step, {mode}, inputs resident in HBM" + (f", steps submitted back to back ({in_flight} in flight)" if (args.overlap_steps and args.effort) else "")
+                       if not args.host_inputs else f"{B} x {H}x{W} SYN-1 frames per GPU per step, {mode}, host inputs (PCIe-inclusive)",
+                       "frames_per_gpu": B, "images_in_flight": slots, "host_coder_threads_per_gpu": coders, "coded_bin_buffers_in_hbm": host_buffers, "steps_overlapped": bool(args.overlap_steps and args.effort), "steps_in_flight": in_flight if args.effort else 1,
                        "device_coder_pack_threads": dev_packs,
                        "parallelism": f"image-per-GPU x{world}, RCCL gather of streams" if world > 1 else "single GPU",
-                       "host": host_description()},
+                       "host": dict(host_description(), cpu_slice=share_how, pinned_host_memory=pinned)},
             "bit_exact": bit_exact, "bit_exact_checks": checks, "gathered_ok": gathered_ok,
             "bits_per_pixel": round(8.0 * float(np.mean(lens)) / (H * W), 4),
-            "bins_per_pixel": round((bins + (dev_stats["bins"] if dev_stats else 0.0)) / (H * W * B * steps_counted), 3),
-            "host_coder_Mbins_per_s_per_thread": round(bins / coder_s / 1e6, 1) if coder_s > 0 else None,
-            "device_coder": dev_stats,
-            # the device -> host feed of the host coder stage: 2 bytes per coded bin over PCIe (spec 63 GB/s)
-            # coded bins cross PCIe as 13-bit groups: 64 bins in thirteen 64-bit words (range_coder.h kGroupWords)
-            "d2h_bytes_per_bin": 13.0 / 8.0, "d2h_GB_per_s": round(bins / steps_counted * args.steps * (13.0 / 8.0) / dt / 1e9, 2),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": profiled_traffic(dom, imgs_per_launch),
-                         "launch_ms": round(per_launch[dom], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "images_per_launch": imgs_per_launch},
-            "s1_roofline": {"kernel": "k_predict", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                            "launch_ms": round(per_launch.get("k_predict", 0.0), 4),
-                            "algorithmic_bytes_per_launch": int(5 * H * W * imgs_per_launch),      # 1 B/px read + its 4 B/px record written
-                            "achieved": round(5 * H * W * imgs_per_launch / (per_launch["k_predict"] * 1e-3) / 1e9, 2) if per_launch.get("k_predict") else None,
-                            "frac": round(5 * H * W * imgs_per_launch / (per_launch["k_predict"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if per_launch.get("k_predict") else None},
-            "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
         }
+        if args.effort:
+            line.update({
+                "bins_per_pixel": round((bins + (dev_stats["bins"] if dev_stats else 0.0)) / (H * W * B * steps_counted), 3),
+                "host_coder_Mbins_per_s_per_thread": round(bins / coder_s / 1e6, 1) if coder_s > 0 else None,
+                "device_coder": dev_stats,
+                # coded bins cross PCIe as 13-bit groups: 64 bins in thirteen 64-bit words (range_coder.h kGroupWords)
+                "d2h_bytes_per_bin": 13.0 / 8.0, "d2h_GB_per_s": round(bins / steps_counted * args.steps * (13.0 / 8.0) / dt / 1e9, 2),
+                "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": profiled_traffic(dom, imgs_per_launch),
+                             "traffic_source": "the committed rocprofv3 PMC summary (profiles/*_hbm_traffic.csv), rescaled to this run's frames per launch; not measured in this run",
+                             "launch_ms": round(launch_ms, 4),
+                             "launch_ms_measured": "HIP events inside the timed region" if in_region else "HIP events in the all-stage pass right after the timed region",
+                             "launch_ms_note": f"average over {timed_launches} launches while up to {min(args.groups, slots)} groups share the GPU: it includes the time a launch waits for CUs",
+                             "launch_ms_alone": round(alone_per_launch[dom], 4) if alone_per_launch.get(dom) else None,
+                             "achieved_alone": round((H * W + float(np.mean(lens))) * extra.get("frames_per_launch_alone", 0) / (alone_per_launch[dom] * 1e-3) / 1e9, 3) if alone_per_launch.get(dom) else None,
+                             "algorithmic_bytes_per_launch": int(alg_bytes), "images_per_launch": imgs_per_launch,
+                             "chosen_from": "all 31 stage timers of this run" if all_per_launch else "the stages timed inside the region"},
+                "s1_roofline": {"kernel": "k_predict", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                "launch_ms": round(k_pred_ms, 4), "launch_ms_alone": round(alone_per_launch["k_predict"], 4) if alone_per_launch.get("k_predict") else None,
+                                "algorithmic_bytes_per_launch": int(5 * H * W * imgs_per_launch),      # 1 B/px read + its 4 B/px record written
+                                "achieved": round(5 * H * W * imgs_per_launch / (k_pred_ms * 1e-3) / 1e9, 2) if k_pred_ms else None,
+                                "frac": round(5 * H * W * imgs_per_launch / (k_pred_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_pred_ms else None,
+                                "achieved_alone": round(5 * H * W * extra.get("frames_per_launch_alone", 0) / (alone_per_launch["k_predict"] * 1e-3) / 1e9, 2) if alone_per_launch.get("k_predict") else None},
+                "kernel_ms_per_launch": {k: round(v, 4) for k, v in (all_per_launch or timed_per_launch).items()},
+                "kernel_ms_per_launch_alone": {k: round(v, 4) for k, v in alone_per_launch.items()} or None,
+            })
         line.update(extra)
         if cpu is not None:
             line["cpu_baseline"] = cpu
