@@ -178,7 +178,9 @@ long nblic_amd_serial_launches(nblic_amd_ctx *ctx);
  *   _progress rows finished, bytes emitted so far, their SHA-256, milliseconds spent in the model kernel; returns 1 / 0 / -1.
  *   _checkpoint  writes the checkpoint into buf (cap bytes) and returns its size; with buf == NULL or cap too small it
  *             only returns the size needed.  Valid between two _run calls.
- *   _recon    after the image is finished: the reconstruction the reference leaves in p_img (NBLIC.c:876).            */
+ *   _recon    the reconstruction the reference leaves in p_img (NBLIC.c:876), as far as THIS object has produced it:
+ *             rows [*first_row, *end_row) are written at their place in `plane` (a whole h x w plane); an object resumed
+ *             from a checkpoint starts at the checkpoint's row, the rows before it came out of the earlier objects.   */
 typedef struct nblic_amd_stream nblic_amd_stream;
 nblic_amd_stream *nblic_amd_stream_begin(nblic_amd_ctx *ctx, const unsigned char *img, int img_on_device, int height, int width,
                                          int near, int effort, int band_rows);
@@ -187,7 +189,7 @@ nblic_amd_stream *nblic_amd_stream_resume(nblic_amd_ctx *ctx, const unsigned cha
 int nblic_amd_stream_run(nblic_amd_stream *s, double budget_seconds, unsigned char *out, size_t out_cap, size_t *out_len);
 size_t nblic_amd_stream_checkpoint(nblic_amd_stream *s, void *buf, size_t cap);
 int nblic_amd_stream_progress(nblic_amd_stream *s, int *rows_done, unsigned long long *bytes_total, unsigned char sha256[32], double *model_ms);
-int nblic_amd_stream_recon(nblic_amd_stream *s, unsigned char *recon);
+int nblic_amd_stream_recon(nblic_amd_stream *s, unsigned char *plane, int *first_row, int *end_row);
 void nblic_amd_stream_end(nblic_amd_stream *s);
 
 /* The reference's decoders take no stream length (src/NBLIC.h:72, src/QNBLIC.h:16).  NBLICdecompress / QNBLICdecompress

@@ -137,7 +137,7 @@ def load_library() -> C.CDLL:
     lib.nblic_amd_stream_progress.restype = C.c_int
     lib.nblic_amd_stream_progress.argtypes = [C.c_void_p, ip, C.POINTER(C.c_ulonglong), C.c_void_p, C.POINTER(C.c_double)]
     lib.nblic_amd_stream_recon.restype = C.c_int
-    lib.nblic_amd_stream_recon.argtypes = [C.c_void_p, C.c_void_p]
+    lib.nblic_amd_stream_recon.argtypes = [C.c_void_p, C.c_void_p, ip, ip]
     lib.nblic_amd_stream_end.restype = None
     lib.nblic_amd_stream_end.argtypes = [C.c_void_p]
     lib.nblic_amd_enable_timing.restype = None
@@ -604,11 +604,14 @@ class BandStream:
             raise RuntimeError("nblic_amd_stream_checkpoint failed")
         return buf.tobytes()
 
-    def recon(self) -> np.ndarray:
-        rec = np.empty_like(self.img)
-        if self.lib.nblic_amd_stream_recon(self.handle, C.c_void_p(rec.ctypes.data)) != 0:
-            raise RuntimeError("nblic_amd_stream_recon: the image is not finished")
-        return rec
+    def recon(self, plane: Optional[np.ndarray] = None) -> Tuple[np.ndarray, int, int]:
+        """Writes the rows this object has coded so far into `plane` (a whole h x w array, allocated if None);
+        returns (plane, first_row, end_row).  After a resume the earlier rows came out of the earlier objects."""
+        rec = np.zeros_like(self.img) if plane is None else plane
+        a, b = C.c_int(), C.c_int()
+        if self.lib.nblic_amd_stream_recon(self.handle, C.c_void_p(rec.ctypes.data), C.byref(a), C.byref(b)) != 0:
+            raise RuntimeError("nblic_amd_stream_recon failed")
+        return rec, a.value, b.value
 
     def close(self):
         if self.handle:

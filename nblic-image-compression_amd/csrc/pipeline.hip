@@ -1490,6 +1490,7 @@ struct nblic_amd_stream {
     nblic_amd_ctx *c = nullptr;
     int gid = -1;
     int h = 0, w = 0, near = 0, effort = 1, k_step = 3, band_rows = 1, next_row = 0;
+    int first_row = 0;                                                  // the first row THIS object coded (> 0 after a resume)
     const uint8_t *d_img = nullptr; uint8_t *own_img = nullptr;        // the whole plane on the device
     uint8_t *d_recon = nullptr;                                         // whole reconstruction (near > 0 or rows too wide for LDS)
     double *d_stats = nullptr; size_t stats_bytes = 0;                  // [B | F], efforts 2 / 3
@@ -1665,7 +1666,7 @@ static nblic_amd_stream *stream_resume(nblic_amd_ctx *c, const unsigned char *im
     if (ck_len != stream_checkpoint_bytes(s) || H.stats_bytes != s->stats_bytes / 2 || H.next_row < 0 || H.next_row > H.h) { stream_free(s); return nullptr; }
     Group &g = c->groups[size_t(s->gid)];
     Slot &sl = g.slots[0];
-    s->next_row = H.next_row; s->lo = H.lo; s->hi = H.hi; s->bytes_total = H.bytes_total; s->sha = H.sha;
+    s->next_row = s->first_row = H.next_row; s->lo = H.lo; s->hi = H.hi; s->bytes_total = H.bytes_total; s->sha = H.sha;
     s->finished = false;
     const uint8_t *p = static_cast<const uint8_t *>(ck) + sizeof H;
     bool ok = hipStreamSynchronize(g.stream) == hipSuccess;
@@ -1991,10 +1992,14 @@ int nblic_amd_stream_progress(nblic_amd_stream *s, int *rows_done, unsigned long
     if (model_ms) *model_ms = s->model_ms;
     return s->failed ? -1 : (s->finished ? 1 : 0);
 }
-int nblic_amd_stream_recon(nblic_amd_stream *s, unsigned char *recon) {
-    if (!s || !recon || !s->finished || hipSetDevice(s->c->device) != hipSuccess) return -1;
-    const size_t n = size_t(s->h) * size_t(s->w);
-    return hipMemcpy(recon, s->near > 0 ? s->d_recon : s->d_img, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;    // lossless: the input (NBLIC.c:876)
+int nblic_amd_stream_recon(nblic_amd_stream *s, unsigned char *plane, int *first_row, int *end_row) {
+    if (!s || !plane || s->failed || hipSetDevice(s->c->device) != hipSuccess) return -1;
+    if (first_row) *first_row = s->first_row;
+    if (end_row) *end_row = s->next_row;
+    const size_t at = size_t(s->first_row) * size_t(s->w), n = size_t(s->next_row - s->first_row) * size_t(s->w);
+    if (n == 0) return 0;
+    // lossless: the reconstruction IS the input (NBLIC.c:876 rewrites the same bytes)
+    return hipMemcpy(plane + at, (s->near > 0 ? s->d_recon : s->d_img) + at, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 void nblic_amd_stream_end(nblic_amd_stream *s) { stream_free(s); }
 

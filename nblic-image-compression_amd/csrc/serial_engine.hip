@@ -776,10 +776,102 @@ __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restric
 // and a stream that is still being fed is only ever left in front of a row (kStarved).
 struct QDecodeLds {
     int ctx[3072];
-    uint16_t freq[12 * 256], start[12 * 256 + 1];
+    uint32_t span[12 * 256 + 2];             // per (level, symbol): first slot | first slot of the next symbol << 16 (the histograms sum to 2^15)
     uint8_t coarse[12][256];
     uint32_t sbuf[256];
 };
+
+// What a pixel costs here is the chain  rANS state -> symbol -> pixel -> error -> (next pixel's level) -> ...  with a
+// dependent LDS round trip (~64 cycles) at every table lookup, and the ~200 instructions of the predictor next to it.
+// So: the level (cheap, needs only the taps and the last error) is computed FIRST and the symbol search started from it
+// -- one coarse lookup, then ONE 8-byte read that brings the boundaries of three consecutive symbols (the frequency is
+// their difference: no second table) -- while the seven-direction predictor runs; the context bias is looked up when the
+// prediction is there, and only the pixel itself needs both chains.  The row loops are straight-line code: taps from the
+// register window for rows >= 2 of an image whose rows fit in LDS (the usual case), a generic accessor otherwise.
+struct QRans {
+    uint32_t x;
+    __device__ __forceinline__ int symbol(const QDecodeLds &S, int qd, StreamWindow &sw) {
+        const uint32_t low = x & 32767u;
+        int y = S.coarse[qd][low >> 7];
+        uint32_t s0, s1;
+        for (;;) {                                                       // symbols with no slots are stepped over; cumulative starts are <= 2^15
+            const uint32_t p0 = S.span[qd * 256 + y], p1 = S.span[qd * 256 + y + 1];
+            const uint32_t e0 = p0 >> 16, e1 = p1 >> 16;
+            if (low < e0 || y >= 255) { s0 = p0 & 0xFFFFu; s1 = e0; break; }
+            if (low < e1 || y >= 254) { y += 1; s0 = e0; s1 = e1; break; }
+            y += 2;
+        }
+        x = (x >> 15) * (s1 - s0) + low - s0;
+        if (x < 65536u) { const uint32_t lo = sw.next(); x = (x << 16) | lo | (sw.next() << 8); }
+        return y;
+    }
+};
+
+template <bool CACHED>
+__device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const SerialJob &J, const int rs, const int i0, const int i1,
+                                            StreamWindow &sw, QRans &rans, const bool final_, const size_t row_need, int &stop) {
+    const int lane = int(threadIdx.x), w = J.w;
+    const auto out = gp(J.recon);
+    if (CACHED && i0 > 0) {
+        for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
+            uint8_t *dst = rows + (r % 3) * rs;
+            for (int c = lane; c < w; c += 64) dst[c] = out[size_t(r) * size_t(w) + c];
+        }
+        wave_sync();
+    }
+    int i = i0;
+    stop = kRunning;
+    for (; i < i1; i++) {
+        if (!final_ && sw.len - sw.pos < row_need) { stop = kStarved; break; }
+        uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
+        const size_t row_at = size_t(i) * size_t(w);
+        int err = 0;
+        auto pixel = [&](const Taps &n, int j) {                         // returns the decoded pixel
+            const int qd = level_q(n, err);
+            const int y = rans.symbol(S, qd, sw);                        // independent of the prediction: its lookups overlap the predictor
+            const int px0 = predict_q(n);
+            const int adr = context_address_q(n, qd, px0);
+            const int v = S.ctx[adr];
+            const int sign = (v >> 10) & 1;
+            const int px = iclip(px0 + (v >> 11) + sign, 0, kMaxVal);
+            const int px_out = symbol_to_pixel(y, px, sign, 0);
+            err = px_out - px0;
+            S.ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
+            (void)j;
+            return px_out;
+        };
+        if (CACHED && i >= 2) {
+            TapWindow tw;
+            tw.row_start(r0, r1, r2, w);
+            const int u0 = r1[0];
+            for (int j = 0; j < w; j++) {
+                Taps n;
+                n.a = j >= 1 ? tw.A : u0; n.e = j >= 2 ? tw.E : u0;
+                n.b = tw.B; n.c = tw.C; n.d = tw.D; n.q = tw.Q; n.f = tw.F; n.g = tw.G; n.h = tw.H; n.r = tw.R; n.s = tw.S; n.t = 0;
+                const int px_out = pixel(n, j);
+                r0[j] = uint8_t(px_out);
+                tw.advance(r1, r2, w, j, px_out);
+                if (sw.dry) break;
+            }
+        } else {
+            auto pix = [&](int r, int c) {
+                if (CACHED) return int((r == i ? r0 : (r == i - 1 ? r1 : r2))[c]);
+                return int(out[size_t(r) * size_t(w) + size_t(c)]);
+            };
+            for (int j = 0; j < w; j++) {
+                const int px_out = pixel(sample_taps_q(pix, w, i, j), j);
+                if (CACHED) r0[j] = uint8_t(px_out); else { out[row_at + j] = uint8_t(px_out); __threadfence_block(); }
+                if (sw.dry) break;
+            }
+        }
+        if (sw.dry) { stop = kFailed; break; }                           // only a final stream can run dry inside a row (a pixel takes one word at most)
+        if (CACHED) {
+            wave_sync();
+            for (int c = lane; c < w; c += 64) out[row_at + c] = r0[c];
+        }
+    }
+    return i;
+}
 
 __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restrict__ jobs, int dyn_bytes) {
     __shared__ QDecodeLds S;
@@ -788,81 +880,33 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restri
     const auto st = gp(J.state);
     const auto st_ctx = gp(reinterpret_cast<int *>(J.state + 1));
     const int lane = int(threadIdx.x), w = J.w, h = J.h;
-    const auto out = gp(J.recon);
     if (st->status != kRunning) return;
     const int i0 = st->next_row, i1 = i0 + J.rows < h ? i0 + J.rows : h;
     const bool final_ = st->final_ != 0;
     const size_t avail = size_t(st->avail) & ~size_t(1), row_need = size_t(2) * size_t(w) + 8;
     if (!final_ && (avail < size_t(st->pos) || avail - size_t(st->pos) < row_need)) { if (lane == 0) st->status = kStarved; return; }
     for (int k = lane; k < 3072; k += 64) {
-        S.ctx[k] = i0 ? st_ctx[k] : 0; S.freq[k] = uint16_t(gp(J.q_freq)[k]); S.start[k] = uint16_t(gp(J.q_start)[k]);
+        const uint32_t s0 = gp(J.q_start)[k], f = gp(J.q_freq)[k];
+        S.ctx[k] = i0 ? st_ctx[k] : 0;
+        S.span[k] = (s0 & 0xFFFFu) | (((s0 + f) & 0xFFFFu) << 16);
         (&S.coarse[0][0])[k] = gp(J.q_slot)[size_t(k >> 8) * 32768 + size_t(k & 255) * 128];
     }
-    if (lane == 0) S.start[3072] = 0;
+    if (lane < 2) S.span[3072 + lane] = 0;
     wave_sync();
     const int rs = (w + 15) & ~15;
-    const bool cached = 3 * rs <= dyn_bytes;
     StreamWindow sw;
     sw.start(J.stream, avail, size_t(st->pos), S.sbuf);                   // a fresh image: the host has set pos to the first word after the tables
     auto next_word = [&]() { const uint32_t lo = sw.next(); return lo | (sw.next() << 8); };
-    uint32_t x;
-    if (i0 == 0) { x = next_word() << 16; x |= next_word(); }
-    else x = st->lo;
-    if (cached && i0 > 0) {
-        for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
-            uint8_t *dst = rows + (r % 3) * rs;
-            for (int c = lane; c < w; c += 64) dst[c] = out[size_t(r) * size_t(w) + c];
-        }
-        wave_sync();
-    }
-    int i = i0, stop = kRunning;
-    for (; i < i1; i++) {
-        if (!final_ && sw.len - sw.pos < row_need) { stop = kStarved; break; }
-        uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
-        auto pix = [&](int r, int c) {
-            if (cached) return int((r == i ? r0 : (r == i - 1 ? r1 : r2))[c]);
-            return int(out[size_t(r) * size_t(w) + size_t(c)]);
-        };
-        const size_t row_at = size_t(i) * size_t(w);
-        const bool windowed = cached && i >= 2;
-        TapWindow tw;
-        int u0 = 0;
-        if (windowed) { tw.row_start(r0, r1, r2, w); u0 = r1[0]; }
-        int err = 0;
-        for (int j = 0; j < w; j++) {
-            Taps n;
-            if (windowed) {
-                n.a = j >= 1 ? tw.A : u0; n.e = j >= 2 ? tw.E : u0;
-                n.b = tw.B; n.c = tw.C; n.d = tw.D; n.q = tw.Q; n.f = tw.F; n.g = tw.G; n.h = tw.H; n.r = tw.R; n.s = tw.S; n.t = 0;
-            } else {
-                n = sample_taps_q(pix, w, i, j);
-            }
-            const int px0 = predict_q(n), qd = level_q(n, err);
-            const int adr = context_address_q(n, qd, px0);
-            const int v = S.ctx[adr];
-            const int sign = (v >> 10) & 1;
-            const int px = iclip(px0 + (v >> 11) + sign, 0, kMaxVal);
-            const uint32_t low = x & 32767u;
-            int y = S.coarse[qd][low >> 7];
-            while (y < 255 && uint32_t(S.start[qd * 256 + y + 1]) <= low) y++;      // symbols with no slots are stepped over; cumulative starts are <= 2^15
-            x = (x >> 15) * uint32_t(S.freq[qd * 256 + y]) + low - uint32_t(S.start[qd * 256 + y]);
-            if (x < 65536u) x = (x << 16) | next_word();
-            const int px_out = symbol_to_pixel(y, px, sign, 0);
-            err = px_out - px0;
-            S.ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
-            if (cached) { r0[j] = uint8_t(px_out); if (windowed) tw.advance(r1, r2, w, j, px_out); } else { out[row_at + j] = uint8_t(px_out); __threadfence_block(); }
-            if (sw.dry) break;
-        }
-        if (sw.dry) { stop = kFailed; break; }                           // only a final stream can run dry inside a row (see above)
-        if (cached) {
-            wave_sync();
-            for (int c = lane; c < w; c += 64) out[row_at + c] = r0[c];
-        }
-    }
+    QRans rans;
+    if (i0 == 0) { rans.x = next_word() << 16; rans.x |= next_word(); }
+    else rans.x = st->lo;
+    int stop = kRunning, at;
+    if (3 * rs <= dyn_bytes) at = qdecode_rows<true>(S, rows, J, rs, i0, i1, sw, rans, final_, row_need, stop);
+    else at = qdecode_rows<false>(S, rows, J, rs, i0, i1, sw, rans, final_, row_need, stop);
     wave_sync();
     if (stop == kFailed || sw.dry) { if (lane == 0) st->status = kFailed; return; }
-    if (i < h) for (int k = lane; k < 3072; k += 64) st_ctx[k] = S.ctx[k];
-    if (lane == 0) { st->next_row = i; st->pos = sw.pos; st->lo = x; st->status = i >= h ? kDone : stop; }
+    if (at < h) for (int k = lane; k < 3072; k += 64) st_ctx[k] = S.ctx[k];
+    if (lane == 0) { st->next_row = at; st->pos = sw.pos; st->lo = rans.x; st->status = at >= h ? kDone : stop; }
 }
 
 // ---- self-test: the double-carried divisions against 64-bit integers ------------------------------

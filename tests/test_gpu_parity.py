@@ -145,6 +145,51 @@ def test_config2_4096_golden_and_round_trip(gpu_ctx, golden, oracle):
     assert dec is not None and np.array_equal(dec[0], img)
 
 
+def test_gpu_decoders_at_baseline_sizes(gpu_ctx, pkg, golden):
+    """The GPU decoders (k_serial_decode, k_serial_qdecode; resumable launches) on BASELINE-sized streams: the
+    config-2 stream (4096 x 4096 -n0 -e1, 8,900,446 bytes, 77d18ede...) and the 4096 x 4096 effort-0 stream
+    (ed712408...), both produced on the GPU and checked against the reference's golden hashes first, decoded in one
+    nblic_amd_decode_batch call back to the input; then the config-2 stream through the drop-in NBLICdecompress,
+    which fetches it on demand."""
+    from oracle.oracle import syn1
+    manifest, _ = golden
+    img = syn1(4096, 4096, 1)
+    s1 = gpu_ctx.encode_batch([img])[0]
+    s0 = gpu_ctx.qencode_batch([img])[0]
+    assert sha(s1) == manifest["large"]["syn1s1_4096x4096_n0_e1"]["sha256"] and sha(s0) == manifest["large"]["syn1s1_4096x4096_q0"]["sha256"]
+    before = gpu_ctx.serial_launches()
+    dec = gpu_ctx.decode_batch([s1, s0])
+    assert gpu_ctx.serial_launches() - before >= 8                        # 4 Mpixel per launch: resumed launches, no kernel of tens of seconds
+    assert dec[0] is not None and np.array_equal(dec[0][0], img) and dec[0][1:] == (0, 1)
+    assert dec[1] is not None and np.array_equal(dec[1][0], img)
+    d = pkg.decompress(s1)
+    assert d is not None and np.array_equal(d[0], img)
+    assert pkg.last_fed_bytes() <= len(s1) + (1 << 20) + 4 * 4096 + 1024
+
+
+def test_config4_8192_n2e2_full_size(gpu_ctx, pkg, golden):
+    """BASELINE config 4 at full size: 8192 x 8192 SYN-1, -n2 -e2 (near-lossless, least-squares predictor), worked
+    through in row bands (nblic_amd_stream: bounded workspace, one model launch per band).  Stream 16,832,870 bytes,
+    597d85ec... and the reconstruction (max error 2) from the compiled reference.  ~3 minutes."""
+    from oracle.oracle import syn1
+    manifest, _ = golden
+    m = manifest["serial"]["syn1s1_8192x8192_n2_e2"]
+    assert m["sha256"].startswith("597d85ec934d8b78") and m["len"] == 16832870
+    img = syn1(8192, 8192, 1)
+    ctx = pkg.Context(device=0, n_slots=2, n_coders=1)
+    try:
+        st = ctx.stream(img, 2, 2)
+        done, s = st.run()
+        prog = st.progress()
+        rec, r0, r1 = st.recon()
+        st.close()
+    finally:
+        ctx.close()
+    assert done and (len(s), sha(s)) == (m["len"], m["sha256"]) and prog["sha256"] == m["sha256"]
+    assert (r0, r1) == (0, 8192) and sha(rec.tobytes()) == m["recon_sha256"]
+    assert int(np.abs(rec.astype(np.int16) - img.astype(np.int16)).max()) == 2
+
+
 def test_device_resident_inputs(gpu_ctx, oracle):
     torch = pytest.importorskip("torch")
     from oracle.oracle import syn1

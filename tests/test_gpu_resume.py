@@ -158,11 +158,11 @@ def test_band_stream_equals_one_piece_and_survives_checkpoints(gpu_ctx, pkg, ora
             done, whole = st.run()
             assert done and whole == want, (img.shape, near, effort)
             assert st.progress()["sha256"] == hashlib.sha256(want).hexdigest()
-            assert np.array_equal(st.recon(), wrec)
+            assert np.array_equal(st.recon()[0], wrec)
             st.close()
         finally:
             ctx.close()
-        pieces, ck, steps = [], None, 0
+        pieces, ck, steps, rec = [], None, 0, np.zeros_like(img)
         while True:
             ctx = pkg.Context(device=0, n_slots=2, n_coders=1)
             try:
@@ -170,9 +170,10 @@ def test_band_stream_equals_one_piece_and_survives_checkpoints(gpu_ctx, pkg, ora
                 done, piece = st.run(1e-9)                               # the budget is spent after one band
                 pieces.append(piece)
                 steps += 1
+                _, r0, r1 = st.recon(rec)                                # every object hands over the rows IT coded
+                assert (r0, r1) == ((steps - 1) * band, min(steps * band, img.shape[0]))
                 if done:
                     prog = st.progress()
-                    rec = st.recon()
                     st.close()
                     break
                 ck = st.checkpoint()

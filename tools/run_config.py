@@ -13,6 +13,7 @@ the whole stream is known at the end although no run ever held all of it.
     python tools/run_config.py --shape 64x16384 --near 0 --effort 3 [--one-piece]
 """
 import argparse, hashlib, importlib, json, os, sys, time
+import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -81,13 +82,19 @@ else:
         print(json.dumps(line), flush=True)
         st.close(); ctx.close()
         sys.exit(3)
-    rec = st.recon()
+    rec, r0, r1 = st.recon()
     if ck is None:
         stream_bytes = piece
+    elif near > 0:
+        line["recon_rows_checked"] = [r0, r1]                # a resumed run holds only the rows it coded itself
+    else:
+        rec = img                                            # lossless: the reconstruction is the input (NBLIC.c:876)
     st.close()
 total_s = sum(r["seconds"] for r in line.get("runs", [])) or dt
 line.update({"encode_seconds": round(total_s, 2), "encode_us_per_px": round(total_s / (h * w) * 1e6, 3), "encode_Mpixel_per_s": round(h * w / total_s / 1e6, 3),
-             "recon_sha256": hashlib.sha256(rec.tobytes()).hexdigest(), "max_abs_error": int(abs(rec.astype(int) - img.astype(int)).max())})
+             "recon_sha256": hashlib.sha256(rec.tobytes()).hexdigest()})
+rows = slice(*line["recon_rows_checked"]) if "recon_rows_checked" in line else slice(0, h)
+line["max_abs_error"] = int(abs(rec[rows].astype(np.int16) - img[rows].astype(np.int16)).max())
 if gold:
     line["golden"] = {"bytes": gold["len"], "sha256": gold["sha256"], "reference_thread_seconds": gold.get("ref_seconds"), "limit_raised": gold.get("limit_raised")}
     line["bit_exact"] = (line["bytes"] == gold["len"] and line["sha256"] == gold["sha256"] and line["recon_sha256"] == gold["recon_sha256"])
