@@ -2033,6 +2033,18 @@ int NBLICcompress(int verbose, unsigned char *p_buf, unsigned char *p_img, int h
     nblic_amd_ctx *c = default_ctx();
     if (!c) return -1;
     if (!size_ok(height, width, c->max_px)) return -1;                       // NBLIC.h:31 unless nblic_amd_set_max_pixels(NULL, ...) raised it
+    const bool serial_mode = !(*p_near == 0 && *p_effort == 1);
+    if (serial_mode && size_t(height) * size_t(width) > (size_t(1) << 23)) {
+        // a large image of a raster-serial mode: row bands (one band's workspace instead of 120 bytes per pixel of the
+        // whole image, one model launch per band) -- the same bytes
+        nblic_amd_stream *st = stream_open(c, p_img, false, height, width, *p_near, *p_effort, 0);
+        if (!st) return -1;
+        size_t n = 0;
+        int rc = stream_run(st, 0.0, p_buf, size_t(1) << 46, &n);            // the reference ABI carries no capacity
+        if (rc == 1 && *p_near > 0) { int r0 = 0, r1 = 0; rc = nblic_amd_stream_recon(st, p_img, &r0, &r1) == 0 ? 1 : -1; }   // NBLIC.c:876
+        stream_free(st);
+        return rc == 1 && n < (size_t(1) << 31) ? int(n) : -1;
+    }
     const unsigned char *imgs[1] = {p_img};
     unsigned char *outs[1] = {p_buf}, *recons[1] = {p_img};
     size_t caps[1] = {SIZE_MAX};

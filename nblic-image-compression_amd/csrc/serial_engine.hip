@@ -76,6 +76,28 @@ __device__ __forceinline__ double bcast_half(double v) {
     const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double(int(b[HALF]), int(a[HALF]));
 }
+// The same among the FOUR 16-lane rows of the wave (v_permlane16_swap_b32 swaps the odd rows of its first operand with
+// the even rows of its second: with the same value in both, the first result is rows [0 0 2 2], the second [1 1 3 3]).
+template <int ROW>
+__device__ __forceinline__ double bcast_row(double v) {
+    const unsigned lo = unsigned(__double2loint(v)), hi = unsigned(__double2hiint(v));
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const unsigned tl = a[ROW & 1], th = b[ROW & 1];
+    const auto c = __builtin_amdgcn_permlane32_swap(tl, tl, false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(th, th, false, false);
+    return __hiloint2double(int(d[ROW >> 1]), int(c[ROW >> 1]));
+}
+// maximum / sum over the EIGHT lanes of a half-row: xor 1, xor 2 inside the quads, then the mirror image of the half-row
+constexpr int kQuadX1 = 0xB1, kQuadX2 = 0x4E, kHalfMirror = 0x141;
+__device__ __forceinline__ double half_row_max(double v) {
+    v = max_f64(v, dpp_f64<kQuadX1>(v)); v = max_f64(v, dpp_f64<kQuadX2>(v)); v = max_f64(v, dpp_f64<kHalfMirror>(v));
+    return v;
+}
+__device__ __forceinline__ double half_row_sum(double v) {
+    v += dpp_f64<kQuadX1>(v); v += dpp_f64<kQuadX2>(v); v += dpp_f64<kHalfMirror>(v);
+    return v;
+}
 // value of lane (byte_addr / 4)
 __device__ __forceinline__ double fetch_f64(double v, int byte_addr) {
     const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
@@ -185,21 +207,83 @@ __device__ __noinline__ int lsq_solve_int(LsqLds &S, int n, i64 bias, i64 *px_q1
     return 1;
 }
 
-// ---- least squares in registers: the pixel's two systems side by side, columns split over the half-waves ----
-// Lane layout: row = lane & 15 of system (lane >> 4) & 1; half = lane >> 5 owns the columns of its parity: slot s of
-// M holds column 2 s + half of the augmented row [A | b] (column N = the right-hand side, in half 0; half 1's last
-// slot is unused and stays 0).  So the four 16-lane rows of the wave are (system 0, even columns), (system 1, even),
-// (system 0, odd), (system 1, odd), and an elimination step costs ceil((N - k) / 2) multiply-divides instead of N - k.
-// Per step the pivot column is handed to the other half with v_permlane32_swap (no LDS), every 16-lane row then finds
-// the pivot for itself (DPP) and fetches the pivot row's entries of ITS columns (ds_bpermute inside the row).
-// Rows never move: each carries its position.  The broadcast columns are kept: once a row has been placed its
-// entries no longer change, so column k as seen at step k is what the back substitution needs above the diagonal.
-// Returns the Q12 prediction of the lane's system in every lane of its 16-lane row; ok = 0: a pivot was zero (NBLIC.c:118).
+// ---- least squares in registers: the pixel's two systems side by side, their columns split over the wave ----
+// Lanes: R per (system, column group) -- R = 16 for N = 10 (two column groups: the half-waves), R = 8 for N = 6 (four
+// column groups: the 16-lane rows) --, row = lane & (R - 1), system = (lane / R) & 1, column group cg = lane / (2 R).
+// Slot s of M holds column G s + cg of the augmented row [A | b] (column N = the right-hand side; columns beyond it
+// do not exist and their slots stay 0), so an elimination step costs ceil((N - k) / G) multiply-divides instead of
+// N - k.  Per step the pivot column is handed to the other column groups with v_permlane32_swap / v_permlane16_swap
+// (no LDS), every group then finds the pivot for itself (DPP) and fetches the pivot row's entries of ITS columns
+// (ds_bpermute inside the group).  Rows never move: each carries its position.  The broadcast columns are kept: once
+// a row has been placed its entries no longer change, so column k as seen at step k is what the back substitution
+// needs above the diagonal.
+// Returns the Q12 prediction of the lane's system in every lane of its group; ok = 0: a pivot was zero (NBLIC.c:118).
 template <int N>
-__device__ __forceinline__ double lsq_solve_split(double (&M)[(N + 2) / 2], const int row, const int half, const int row_base4,
+struct SplitLayout {
+    static constexpr int R = N <= 8 ? 8 : 16, G = 64 / (2 * R), kS = (N + G) / G;       // kS = ceil((N + 1) / G)
+};
+template <int N, int CG>
+__device__ __forceinline__ double bcast_group(double v) {
+    if constexpr (SplitLayout<N>::G == 2) return bcast_half<CG>(v);
+    else return bcast_row<CG>(v);
+}
+template <int N>
+__device__ __forceinline__ double group_max(double v) { if constexpr (SplitLayout<N>::R == 16) return row_max(v); else return half_row_max(v); }
+template <int N>
+__device__ __forceinline__ double group_sum(double v) { if constexpr (SplitLayout<N>::R == 16) return row_sum(v); else return half_row_sum(v); }
+// column k of the system, from the group that owns it, in every group (k is a constant after unrolling)
+template <int N, int K>
+__device__ __forceinline__ double column_everywhere(const double (&M)[SplitLayout<N>::kS]) {
+    return bcast_group<N, K % SplitLayout<N>::G>(M[K / SplitLayout<N>::G]);
+}
+
+template <int N, int K>
+__device__ __forceinline__ void eliminate_step(double (&M)[SplitLayout<N>::kS], double (&col)[N], int (&at)[N], int &at_sum, int &pos, double &diag, int &ok,
+                                               const int live, const int row, const int cg, const int group_base4, lsq::Guard &g) {
+    using L = SplitLayout<N>;
+    constexpr int k = K;
+    const double ck = column_everywhere<N, K>(M);
+    col[k] = ck;
+    // every lane prepares the reciprocal of ITS candidate while the pivot search runs: the winner's is fetched with
+    // its value, and the reciprocal's dependent chain is off the step's critical path
+    const double raw_c = lsq::recip_raw(ck);
+    // pivot: largest |entry| of column k among the rows at positions >= k, first position wins (NBLIC.c:121-127)
+    const double key = group_max<N>((live & (pos >= k)) ? fma(fabs(ck), 256.0, double((15 - pos) * 16 + row)) : -1.0);
+    const int tag = int(fma(-256.0, floor(key * (1.0 / 256.0)), key));
+    const int c = tag & 15, pc = 15 - (tag >> 4);
+    const int src = group_base4 | (c << 2);
+    constexpr int s0 = (k + 1) / L::G;                                   // first slot with a column beyond k in some group
+    const double d = fetch_f64(ck, src);
+    const lsq::Recip rc = lsq::recip_of_raw(fetch_f64(raw_c, src));
+    double prow[L::kS];                                                  // the pivot row's entries of this lane's columns: all requests go out together
+#pragma unroll
+    for (int s = s0; s < L::kS; s++) prow[s] = fetch_f64(M[s], src);
+    at[k] = c; at_sum += c;
+    pos = pos == k ? pc : pos;                                           // the row that sat at k takes the pivot's place
+    pos = (live & (row == c)) ? k : pos;
+    diag = pos == k ? d : diag;
+    ok &= int(d != 0.0);
+    const double l = (live & (pos > k)) ? ck : 0.0;                      // rows already placed take no part: their quotient is 0
+#pragma unroll
+    for (int s = s0; s < L::kS; s++) {
+        // slot s0 may still hold columns <= k in the lower groups: they are done with (the reference never reads them again)
+        const double ls = (s == s0 && L::G * s0 <= k) ? ((L::G * s0 + cg > k) ? l : 0.0) : l;
+        M[s] -= lsq::muldiv_trunc(prow[s], ls, d, rc, g);
+        g.see_entry(M[s]);
+    }
+}
+template <int N, int K>
+__device__ __forceinline__ void eliminate_from(double (&M)[SplitLayout<N>::kS], double (&col)[N], int (&at)[N], int &at_sum, int &pos, double &diag, int &ok,
+                                               const int live, const int row, const int cg, const int group_base4, lsq::Guard &g) {
+    if constexpr (K + 1 < N) {
+        eliminate_step<N, K>(M, col, at, at_sum, pos, diag, ok, live, row, cg, group_base4, g);
+        eliminate_from<N, K + 1>(M, col, at, at_sum, pos, diag, ok, live, row, cg, group_base4, g);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ double lsq_solve_split(double (&M)[SplitLayout<N>::kS], const int row, const int cg, const int group_base4,
                                                   const int8_t *vn8, lsq::Guard &g, int &ok) {
-    constexpr int kS = (N + 2) / 2;
-    static_assert((N & 1) == 0, "the right-hand side has to fall to half 0");
     // (flags are ints in vector registers: as booleans they would each pin a scalar register pair for the whole solve)
     const int live = row < N;
     int pos = row, at_sum = 0;
@@ -207,47 +291,16 @@ __device__ __forceinline__ double lsq_solve_split(double (&M)[(N + 2) / 2], cons
     double col[N];
     double diag = 1.0;
     ok = 1;
-#pragma unroll
-    for (int k = 0; k + 1 < N; k++) {
-        const double ck = (k & 1) ? bcast_half<1>(M[k >> 1]) : bcast_half<0>(M[k >> 1]);
-        col[k] = ck;
-        // every lane prepares the reciprocal of ITS candidate while the pivot search runs: the winner's is fetched with
-        // its value, and the reciprocal's dependent chain is off the step's critical path
-        const double raw_c = lsq::recip_raw(ck);
-        // pivot: largest |entry| of column k among the rows at positions >= k, first position wins (NBLIC.c:121-127)
-        const double key = row_max((live & (pos >= k)) ? fma(fabs(ck), 256.0, double((15 - pos) * 16 + row)) : -1.0);
-        const int tag = int(fma(-256.0, floor(key * (1.0 / 256.0)), key));
-        const int c = tag & 15, pc = 15 - (tag >> 4);
-        const int src = row_base4 | (c << 2);
-        const int s0 = (k + 1) >> 1;                                     // first slot with a column beyond k in either half
-        const double d = fetch_f64(ck, src);
-        const lsq::Recip rc = lsq::recip_of_raw(fetch_f64(raw_c, src));
-        double prow[kS];                                                 // the pivot row's entries of this lane's columns: all requests go out together
-#pragma unroll
-        for (int s = s0; s < kS; s++) prow[s] = fetch_f64(M[s], src);
-        at[k] = c; at_sum += c;
-        pos = pos == k ? pc : pos;                                       // the row that sat at k takes the pivot's place
-        pos = (live & (row == c)) ? k : pos;
-        diag = pos == k ? d : diag;
-        ok &= int(d != 0.0);
-        const double l = (live & (pos > k)) ? ck : 0.0;                  // rows already placed take no part: their quotient is 0
-#pragma unroll
-        for (int s = s0; s < kS; s++) {
-            // for even k half 0's slot s0 is the pivot column itself: it is done with (the reference never reads it again)
-            const double ls = (!(k & 1) && s == s0) ? (half ? l : 0.0) : l;
-            M[s] -= lsq::muldiv_trunc(prow[s], ls, d, rc, g);
-            g.see_entry(M[s]);
-        }
-    }
+    eliminate_from<N, 0>(M, col, at, at_sum, pos, diag, ok, live, row, cg, group_base4, g);
     at[N - 1] = N * (N - 1) / 2 - at_sum;
-    col[N - 1] = bcast_half<1>(M[(N - 1) >> 1]);
+    col[N - 1] = column_everywhere<N, N - 1>(M);
     diag = (live & (pos == N - 1)) ? col[N - 1] : diag;
-    double rhs = bcast_half<0>(M[N >> 1]);                               // both halves finish the solve alike
+    double rhs = column_everywhere<N, N>(M);                             // every group finishes the solve alike
     g.see_pivot(diag);                                                   // every divisor of the solve is some row's diagonal entry
     const double raw_own = lsq::recip_raw(diag);                         // every row's own reciprocal at once, fetched below
 #pragma unroll
     for (int k = N - 1; k > 0; k--) {                                     // back substitution on the right-hand side (NBLIC.c:148-158)
-        const int src = row_base4 | (at[k] << 2);
+        const int src = group_base4 | (at[k] << 2);
         const double d = fetch_f64(diag, src), bk = fetch_f64(rhs, src);
         const lsq::Recip rcd = lsq::recip_of_raw(fetch_f64(raw_own, src));
         ok &= int(d != 0.0);
@@ -257,7 +310,7 @@ __device__ __forceinline__ double lsq_solve_split(double (&M)[(N + 2) / 2], cons
     }
     const int v = vn8[live ? pos : 14];
     const double t = lsq::term(live ? rhs : 0.0, v, diag, lsq::recip_of_raw(raw_own), g);     // NBLIC.c:233-236
-    return double(kMid << lsq::kFb1) + row_sum(live ? t : 0.0);
+    return double(kMid << lsq::kFb1) + group_sum<N>(live ? t : 0.0);
 }
 
 // Per-lane description of the one or two statistics entries a lane maintains ([s | b(n) | A(n x n)] order).
@@ -310,23 +363,27 @@ __device__ void lsq_row_prepare(const LsqEntries<N> &en, NB_GLOBAL double *F, NB
 template <int N>
 struct LsqWalk {
     using T = LsqEntries<N>;
-    static constexpr int kS = (N + 2) / 2;                               // column slots per lane (lsq_solve_split)
+    using L = SplitLayout<N>;
+    static constexpr int kS = L::kS;                                     // column slots per lane (lsq_solve_split)
     LsqEntries<N> en;
     double E[T::kSlots], Bj[T::kSlots], Fj[T::kSlots], Bn[T::kSlots], Fn[T::kSlots];
     NB_GLOBAL double *Bst, *Fst;
-    int bias, b1, b2, lane, row, half, row_base4, w;
-    int d_base, d_rhs, diag_slot;                                        // where the lane's slots sit in S.D; which slot (if any) is on the diagonal
+    int bias, b1, b2, lane, row, cg, sys, group_base4, w;
+    int d_base, d_last, diag_slot, last_kind;                            // where the lane's slots sit in S.D; which slot (if any) is on the diagonal; last slot: 0 matrix column, 1 right-hand side, 2 nothing
     int p1, p2;                                                          // Q12 predictions (<= 255 << 12)
     bool ok1, ok2;
 
     __device__ void init(double *stats, int w_, int lane_, int bias_) {
-        lane = lane_; w = w_; row = lane & 15; half = lane >> 5; row_base4 = (lane & 48) << 2;
+        lane = lane_; w = w_; row = lane & (L::R - 1); sys = (lane / L::R) & 1; cg = lane / (2 * L::R); group_base4 = (lane & ~(L::R - 1)) << 2;
         Bst = gp(stats); Fst = gp(stats) + size_t(w) * T::kStride;
         bias = bias_;
         en.init(lane);
         const int r = row < N ? row : N - 1;                             // the idle lanes of a row mirror its last system row (they never take part)
-        d_base = 1 + N + r * N + half; d_rhs = 1 + r;
-        diag_slot = (row < N && ((row - half) & 1) == 0 && row >= half) ? (row - half) >> 1 : -1;
+        d_base = 1 + N + r * N + cg;                                       // slot s: column G s + cg
+        const int last_col = L::G * (kS - 1) + cg;
+        last_kind = last_col < N ? 0 : (last_col == N ? 1 : 2);
+        d_last = last_kind == 0 ? d_base + L::G * (kS - 1) : 1 + r;       // (an address inside S.D in every case)
+        diag_slot = (row < N && row >= cg && (row - cg) % L::G == 0) ? (row - cg) / L::G : -1;
     }
     __device__ __forceinline__ void load_cols(int j, double (&b)[T::kSlots], double (&f)[T::kSlots]) const {
         const int jj = j < w ? j : w - 1;                                 // the prefetch past the row end re-reads the last column
@@ -349,24 +406,28 @@ struct LsqWalk {
     __device__ __forceinline__ void predict(LsqLds &S, int j) {
         load_cols(j + 1, Bn, Fn);                                         // next pixel's columns: a whole pixel ahead of their use
         lsq::bias_pair(bias, b1, b2);
-        const int bs = (lane & 16) ? b2 : b1;
+        const int bs = sys ? b2 : b1;
         const double reg = double(bs * N);
         double M[kS];
 #pragma unroll
-        for (int s = 0; s + 1 < kS; s++) {                                // slots 0 .. kS-2 are matrix columns in both halves
-            M[s] = S.D[d_base + 2 * s];
+        for (int s = 0; s + 1 < kS; s++) {                                // slots 0 .. kS-2 are matrix columns in every column group
+            M[s] = S.D[d_base + L::G * s];
             M[s] = diag_slot == s ? M[s] + reg : M[s];
         }
-        M[kS - 1] = half ? 0.0 : S.D[d_rhs] + double(bs << lsq::kFb3);   // the right-hand side (half 0) / nothing (half 1)
+        {   // the last slot: a matrix column, the right-hand side, or nothing, depending on the lane's column group
+            const double v = S.D[d_last];
+            const double add = last_kind == 1 ? double(bs << lsq::kFb3) : (diag_slot == kS - 1 ? reg : 0.0);
+            M[kS - 1] = last_kind == 2 ? 0.0 : v + add;
+        }
         lsq::Guard g;
         int ok;
-        const double p = lsq_solve_split<N>(M, row, half, row_base4, S.vn8, g, ok);
+        const double p = lsq_solve_split<N>(M, row, cg, group_base4, S.vn8, g, ok);
         const double pc = p < 0.0 ? 0.0 : (p > double(kMaxVal << lsq::kFb1) ? double(kMaxVal << lsq::kFb1) : p);
         const int pi = int(pc);
         const u64 bad = __ballot(!g.ok());
-        p1 = __builtin_amdgcn_readlane(pi, 0); p2 = __builtin_amdgcn_readlane(pi, 16);
+        p1 = __builtin_amdgcn_readlane(pi, 0); p2 = __builtin_amdgcn_readlane(pi, L::R);      // system 0 / system 1 of column group 0
         const u64 okm = __ballot(ok != 0);
-        ok1 = (okm & 1ull) != 0; ok2 = ((okm >> 16) & 1ull) != 0;
+        ok1 = (okm & 1ull) != 0; ok2 = ((okm >> L::R) & 1ull) != 0;
         if (bad) {                                                       // magnitudes left the exact range: integers decide (rare)
             i64 q1 = 0, q2 = 0;
             ok1 = lsq_solve_int(S, N, b1, &q1) != 0;
@@ -932,6 +993,14 @@ __global__ void k_selftest_swap(uint32_t *bad) {
     const double lo = bcast_half<0>(v), hi = bcast_half<1>(v);
     const double base = 1000.0 * double(blockIdx.x + 1) + 0.25;
     if (lo != base + double(lane & 31) || hi != base + double((lane & 31) + 32)) atomicAdd(bad, 1u);
+    const double r0 = bcast_row<0>(v), r1 = bcast_row<1>(v), r2 = bcast_row<2>(v), r3 = bcast_row<3>(v);
+    const double l15 = base + double(lane & 15);
+    if (r0 != l15 || r1 != l15 + 16.0 || r2 != l15 + 32.0 || r3 != l15 + 48.0) atomicAdd(bad, 1u);
+    // the eight-lane reductions: every lane of a half-row ends with the half-row's maximum / sum
+    const double hm = half_row_max(double(lane * 7 % 13)), hs = half_row_sum(double(lane));
+    double want_m = 0.0, want_s = 0.0;
+    for (int k = 0; k < 8; k++) { const int l = (lane & ~7) + k; want_m = want_m > double(l * 7 % 13) ? want_m : double(l * 7 % 13); want_s += double(l); }
+    if (hm != want_m || hs != want_s) atomicAdd(bad, 1u);
 }
 
 int serial_selftest(hipStream_t s) {
