@@ -1025,6 +1025,7 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
     bool idle;
     { std::lock_guard<std::mutex> l(c->fm); idle = c->coding == 0; }
     if (idle) {                                                   // nothing outstanding: start the reporting afresh
+        for (auto &gr : c->groups) gr.tm_pending = false;         // (timer events of earlier batches that nobody collected belong to THEIR figures, not to this batch's)
         for (auto &v : c->stage_ms) v = 0;
         c->stage_launches = 0;
         c->total_bins = 0; c->coder_s = 0; c->pack_bins = 0; c->pack_s = 0; c->wait_s = 0; c->issue_s = 0; c->driver_cpu_s = 0; c->driver_wait_cpu_s = 0; c->driver_launches = 0; for (auto &v : c->takes) v = 0;
