@@ -235,8 +235,8 @@ def host_description():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)       # the coder threads' rings grow (and are page-locked) during the first steps
+    ap.add_argument("--steps", type=int, default=20)       # steps are submitted back to back: the pipeline's fill and drain (~1 s) are inside the region ONCE, so a longer run of steps weighs them less
+    ap.add_argument("--warmup", type=int, default=3)       # the coder threads' rings grow (and are page-locked) during the first steps
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (the pipeline's fill and drain, ~0.1 s + ~0.8 s, are inside every step)")
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)
