@@ -1241,25 +1241,47 @@ __global__ void __launch_bounds__(256) k_counter_probs(const E1Job *__restrict__
 // (4 of 12 bytes per event) -- unless the image has too many touches for 28-bit positions (flag set by the scan).
 __global__ void __launch_bounds__(256) k_mix(const E1Job *__restrict__ jobs) {
     const E1Job &J = jobs[blockIdx.y];
-    const auto tout = gptr(J.b.tout); const auto coded = gptr(J.b.coded);
+    const auto tout = gptr(J.b.tout);
     const auto pos0 = (NB_GLOBAL const uint32_t *)gptr(J.b.tpos);
     const auto pos1 = pos0 + ((size_t(J.n_ev) + 63) & ~size_t(63));
     const uint32_t r = xcd_block() * 256u + threadIdx.x;
-    if (r >= J.n_ev) return;
-    uint32_t p0 = pos0[r], p1 = pos1[r];
-    int qw, bin; bool odd;
-    if (gptr(J.b.totals)[kWideTouchFlag] != 0u) {
-        const uint32_t e = gptr(J.b.events)[r];
-        qw = ev_qw(e); bin = ev_bin(e); odd = (ev_qu(e) & 1) != 0;
-    } else {
-        qw = int((p0 >> kPosBits) | (((p1 >> kPosBits) & 3u) << 4)); bin = int((p1 >> (kPosBits + 2)) & 1u); odd = (p1 >> 31) != 0u;
-        p0 &= kPosMask; p1 &= kPosMask;
-        if (p0 == kPosMask) p0 = kNoTouch;
-        if (p1 == kPosMask) p1 = kNoTouch;
+    if ((r & ~63u) >= J.n_ev) return;                                  // the whole wave is beyond the image's bins
+    uint32_t code = 0;                                                 // prob | bin << 12; 0 beyond the last bin
+    if (r < J.n_ev) {
+        uint32_t p0 = pos0[r], p1 = pos1[r];
+        int qw, bin; bool odd;
+        if (gptr(J.b.totals)[kWideTouchFlag] != 0u) {
+            const uint32_t e = gptr(J.b.events)[r];
+            qw = ev_qw(e); bin = ev_bin(e); odd = (ev_qu(e) & 1) != 0;
+        } else {
+            qw = int((p0 >> kPosBits) | (((p1 >> kPosBits) & 3u) << 4)); bin = int((p1 >> (kPosBits + 2)) & 1u); odd = (p1 >> 31) != 0u;
+            p0 &= kPosMask; p1 &= kPosMask;
+            if (p0 == kPosMask) p0 = kNoTouch;
+            if (p1 == kPosMask) p1 = kNoTouch;
+        }
+        const uint32_t at_u = odd ? p1 : p0, other = odd ? p0 : p1, at_v = other == kNoTouch ? at_u : other;
+        const int pu = tout[at_u], pv = tout[at_v];
+        code = uint32_t(mix_prob(pu, pv, qw)) | (uint32_t(bin) << 12);
     }
-    const uint32_t at_u = odd ? p1 : p0, other = odd ? p0 : p1, at_v = other == kNoTouch ? at_u : other;
-    const int pu = tout[at_u], pv = tout[at_v];
-    coded[r] = pack_coded(mix_prob(pu, pv, qw), bin);
+    const auto rows = gptr(J.pack_rows);
+    if (!J.pack_rows) {                                                // one image on its own: plain 16-bit records for the scalar coder
+        if (r < J.n_ev) gptr(J.b.coded)[r] = uint16_t((code & 0xFFFu) | ((code >> 12) << 15));
+        return;
+    }
+    // The wave holds the 64 bins of ONE group, a bin per lane: lane j < 13 assembles word j of the group (range_coder.h:
+    // codes 4j .. 4j+3 in its low 52 bits; on top the probability of code 52 + j, or -- word 12 -- the twelve bins of
+    // codes 52 .. 63, which are a slice of the wave's ballot) and stores it between the other seven images' words.
+    const int lane = int(threadIdx.x) & 63;
+    const int j = lane < 13 ? lane : 12;
+    const uint32_t c0 = uint32_t(__builtin_amdgcn_ds_bpermute((4 * j + 0) << 2, int(code)));
+    const uint32_t c1 = uint32_t(__builtin_amdgcn_ds_bpermute((4 * j + 1) << 2, int(code)));
+    const uint32_t c2 = uint32_t(__builtin_amdgcn_ds_bpermute((4 * j + 2) << 2, int(code)));
+    const uint32_t c3 = uint32_t(__builtin_amdgcn_ds_bpermute((4 * j + 3) << 2, int(code)));
+    const uint32_t top_prob = uint32_t(__builtin_amdgcn_ds_bpermute((52 + (j < 12 ? j : 0)) << 2, int(code))) & 0xFFFu;
+    const uint64_t ones = __ballot((code >> 12) != 0u);
+    const uint64_t top = j < 12 ? uint64_t(top_prob) : ((ones >> 52) & 0xFFFull);
+    const uint64_t word = uint64_t(c0) | (uint64_t(c1) << 13) | (uint64_t(c2) << 26) | (uint64_t(c3) << 39) | (top << 52);
+    if (lane < 13) rows[(size_t(r >> 6) * 13u + size_t(lane)) * 8u + size_t(J.pack_lane)] = word;
 }
 
 // ---- model state init (NBLIC.c:797-804) ---------------------------------------------------
