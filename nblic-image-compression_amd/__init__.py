@@ -25,7 +25,7 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnblic_amd.so")
+LIB_PATH = os.environ.get("NBLIC_AMD_LIB") or os.path.join(_HERE, "libnblic_amd.so")      # (NBLIC_AMD_LIB: another build of the same ABI, for A/B runs on one box)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "nblic_amd.h")
 
