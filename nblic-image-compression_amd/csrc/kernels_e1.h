@@ -64,14 +64,6 @@ struct E1Job {
     int dbg;             // timing experiments only (NBLIC_AMD_DBG); 0 in normal operation
     int near, k_step;    // serial modes only (the staged -e1 kernels use the lossless constants 0 and 3)
     uint64_t ktab;       // model.h level_shift_table(k_step)
-    // Where k_mix leaves the coded bins.  pack_rows == nullptr: b.coded, one u16 (prob | bin << 15) per bin.  Otherwise the image
-    // is lane pack_lane (0..7) of a PACK of up to eight images of this launch that one AVX-512 register of a host coder
-    // thread will code together, and k_mix writes the form that register consumes (range_coder.h): 64 bins of a lane as
-    // thirteen 64-bit words of 13-bit codes, the eight lanes of a word side by side --
-    // pack_rows[(13 * g + j) * 8 + pack_lane] = word j of bins 64 g .. 64 g + 63.  No second kernel repacks the bins and
-    // they are written once, at 13 bits instead of 16.
-    uint64_t *pack_rows;
-    int pack_lane;
 };
 
 // One HIP event before every kernel launch (and one after the last): interval k is exactly

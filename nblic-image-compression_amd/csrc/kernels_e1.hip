@@ -673,7 +673,6 @@ __device__ __forceinline__ void perm_set(Perm20 &p, int i, int v) {
     if (up) p.hi = w; else p.lo = w;
 }
 
-constexpr int kPackWords = 13;                 // 64-bit words per lane per group of 64 bins (range_coder.h kGroupWords)
 constexpr int kMapLanes = 16;
 __global__ void __launch_bounds__(64) k_mapper_chains(const E1Job *__restrict__ jobs) {
     __shared__ int count[kMapSyms][64];
@@ -1240,15 +1239,16 @@ __global__ void __launch_bounds__(256) k_counter_probs(const E1Job *__restrict__
 // without a second touch (both trees equal, or weight 0) mixes its one P with itself.  The two position words also
 // carry qw, the bin and qu's parity in their top four bits (pack_pos), so the event itself is not read again
 // (4 of 12 bytes per event) -- unless the image has too many touches for 28-bit positions (flag set by the scan).
-// P(bin == 1) | bin << 12 of bin r of job J (0 beyond the image's last bin)
-__device__ __forceinline__ uint32_t mixed_code(const E1Job &J, uint32_t r, bool wide) {
-    if (r >= J.n_ev) return 0u;
-    const auto tout = gptr(J.b.tout);
+__global__ void __launch_bounds__(256) k_mix(const E1Job *__restrict__ jobs) {
+    const E1Job &J = jobs[blockIdx.y];
+    const auto tout = gptr(J.b.tout); const auto coded = gptr(J.b.coded);
     const auto pos0 = (NB_GLOBAL const uint32_t *)gptr(J.b.tpos);
     const auto pos1 = pos0 + ((size_t(J.n_ev) + 63) & ~size_t(63));
+    const uint32_t r = xcd_block() * 256u + threadIdx.x;
+    if (r >= J.n_ev) return;
     uint32_t p0 = pos0[r], p1 = pos1[r];
     int qw, bin; bool odd;
-    if (wide) {
+    if (gptr(J.b.totals)[kWideTouchFlag] != 0u) {
         const uint32_t e = gptr(J.b.events)[r];
         qw = ev_qw(e); bin = ev_bin(e); odd = (ev_qu(e) & 1) != 0;
     } else {
@@ -1259,64 +1259,7 @@ __device__ __forceinline__ uint32_t mixed_code(const E1Job &J, uint32_t r, bool 
     }
     const uint32_t at_u = odd ? p1 : p0, other = odd ? p0 : p1, at_v = other == kNoTouch ? at_u : other;
     const int pu = tout[at_u], pv = tout[at_v];
-    return uint32_t(mix_prob(pu, pv, qw)) | (uint32_t(bin) << 12);
-}
-
-// Images that are coded on their own: one u16 (prob | bin << 15) per bin into b.coded.
-// A lane of a PACK (pack_rows set): the wave holds the 64 bins of one group, a bin per lane; lanes 0..12 assemble the
-// group's thirteen 64-bit words (range_coder.h: codes 4j .. 4j+3 in the low 52 bits; on top the probability of code
-// 52 + j or, word 12, the twelve bins of codes 52 .. 63, a slice of the wave's ballot) and store them back to back
-// -- 104 contiguous bytes -- into the image's OWN stream of groups, which lives in b.tin (the touch payloads are dead
-// by now).  k_pack_rows then lays the eight streams of a pack side by side.
-__global__ void __launch_bounds__(256) k_mix(const E1Job *__restrict__ jobs) {
-    const E1Job &J = jobs[blockIdx.y];
-    const uint32_t r = xcd_block() * 256u + threadIdx.x;
-    if ((r & ~63u) >= J.n_ev) return;                                  // the whole wave is beyond the image's bins
-    const uint32_t code = mixed_code(J, r, gptr(J.b.totals)[kWideTouchFlag] != 0u);
-    if (!J.pack_rows) {
-        if (r < J.n_ev) gptr(J.b.coded)[r] = uint16_t((code & 0xFFFu) | ((code >> 12) << 15));
-        return;
-    }
-    const int lane = int(threadIdx.x) & 63;
-    const int j = lane < 13 ? lane : 12;
-    const uint32_t c0 = uint32_t(__builtin_amdgcn_ds_bpermute((4 * j + 0) << 2, int(code)));
-    const uint32_t c1 = uint32_t(__builtin_amdgcn_ds_bpermute((4 * j + 1) << 2, int(code)));
-    const uint32_t c2 = uint32_t(__builtin_amdgcn_ds_bpermute((4 * j + 2) << 2, int(code)));
-    const uint32_t c3 = uint32_t(__builtin_amdgcn_ds_bpermute((4 * j + 3) << 2, int(code)));
-    const uint32_t top_prob = uint32_t(__builtin_amdgcn_ds_bpermute((52 + (j < 12 ? j : 0)) << 2, int(code))) & 0xFFFu;
-    const uint64_t ones = __ballot((code >> 12) != 0u);
-    const uint64_t top = j < 12 ? uint64_t(top_prob) : ((ones >> 52) & 0xFFFull);
-    const uint64_t word = uint64_t(c0) | (uint64_t(c1) << 13) | (uint64_t(c2) << 26) | (uint64_t(c3) << 39) | (top << 52);
-    if (lane < 13) ((NB_GLOBAL uint64_t *)gptr(J.b.tin))[size_t(r >> 6) * kPackWords + size_t(lane)] = word;
-}
-
-// PACKS: up to eight consecutive jobs of the launch share pack_rows and are coded together by one AVX-512 register of a
-// host coder thread, which consumes, per 64 bins, thirteen 64-bit words per lane with the eight lanes of a word side by
-// side (range_coder.h): rows[(13 g + j) * 8 + lane].  k_mix left every image's groups in a stream of its own (above);
-// this kernel is the transposition: a wave reads the thirteen words of one group from each of the pack's streams (104
-// contiguous bytes each) and writes the group's 832 bytes in one piece.  Pure streaming -- 1.6 bytes per bin in, the same
-// out -- once per group launch, on the group's own stream.
-// (Tried first and measured, same box, alternating runs: k_mix storing each image's words straight between the other
-// images' words -- 8-byte pieces of lines that seven other blocks complete at other times: device side alone 7.24 ->
-// 6.87 Gpx/s; one wave mixing a group of all eight images and writing it whole -- the eight images' position-sorted
-// touch lists are then all hot at once and no longer fit an XCD's L2: k_mix 3.1 -> 4.6 ms per launch, the line 6.47 ->
-// 6.39.  k_mix must walk ONE image at a time.)
-__global__ void __launch_bounds__(256) k_pack_rows(const E1Job *__restrict__ jobs, int n_jobs) {
-    const int first = int(blockIdx.y) * 8;
-    const E1Job &J0 = jobs[first];
-    if (!J0.pack_rows) return;
-    uint32_t most = 0;
-    int cnt = 0;
-    for (int k = 0; k < 8 && first + k < n_jobs && jobs[first + k].pack_rows == J0.pack_rows; k++) { cnt = k + 1; most = max(most, jobs[first + k].n_ev); }
-    const uint32_t groups = (most + 63u) / 64u;
-    // thread t of the pass writes output word t: group t / 104, word (t % 104) / 8 of image (t % 104) % 8
-    const size_t t = size_t(xcd_block()) * 256u + threadIdx.x;
-    if (t >= size_t(groups) * (kPackWords * 8)) return;
-    const uint32_t g = uint32_t(t / (kPackWords * 8)), w = uint32_t(t % (kPackWords * 8));
-    const int k = int(w & 7u), j = int(w >> 3);
-    uint64_t v = 0;
-    if (k < cnt && g * 64u < jobs[first + k].n_ev) v = ((NB_GLOBAL const uint64_t *)gptr(jobs[first + k].b.tin))[size_t(g) * kPackWords + size_t(j)];
-    gptr(J0.pack_rows)[t] = v;
+    coded[r] = pack_coded(mix_prob(pu, pv, qw), bin);
 }
 
 // ---- model state init (NBLIC.c:797-804) ---------------------------------------------------
@@ -1577,14 +1520,7 @@ void e1_launch_back(const E1Job *d_jobs, const E1Job *h_jobs, int n_jobs, hipStr
     mark(); hipLaunchKernelGGL(k_counter_epochs, dim3(4096, n_jobs), dim3(64), 0, s, d_jobs);
     const unsigned max_windows = unsigned(2ull * max_ev / kWin) + 4096u;          // every touch list has <= 2 touches per bin
     mark(); hipLaunchKernelGGL(k_counter_probs, dim3(cdiv(max_windows, 4), n_jobs), dim3(256), 0, s, d_jobs);
-    mark();
-    uint32_t pack_ev = 0;
-    for (int k = 0; k < n_jobs; k++) if (h_jobs[k].pack_rows) pack_ev = h_jobs[k].n_ev > pack_ev ? h_jobs[k].n_ev : pack_ev;
-    hipLaunchKernelGGL(k_mix, dim3(pad8(cdiv(max_ev, 256) ? cdiv(max_ev, 256) : 1), n_jobs), dim3(256), 0, s, d_jobs);
-    if (pack_ev) {
-        const unsigned words = (pack_ev + 63u) / 64u * 104u;
-        hipLaunchKernelGGL(k_pack_rows, dim3(pad8(cdiv(words, 256)), (n_jobs + 7) / 8), dim3(256), 0, s, d_jobs, n_jobs);
-    }
+    mark(); hipLaunchKernelGGL(k_mix, dim3(pad8(cdiv(max_ev, 256) ? cdiv(max_ev, 256) : 1), n_jobs), dim3(256), 0, s, d_jobs);
     mark();                                                     // index 31: end
 }
 

@@ -3,8 +3,8 @@
 //
 // Images in flight are split into GROUPS that share every kernel launch (a driver thread and a HIP
 // stream per group).  A finished image's coded bins (u16 per bin) stay in an HBM buffer of a pool
-// until a coder thread streams them to the host chunk by chunk (13 bits per bin, laid out for its AVX-512
-// lanes by k_mix itself: eight images of a launch are a pack, up to three packs at a time) through its own pinned ring
+// until a coder thread streams them to the host chunk by chunk (packed to 13 bits per bin and laid
+// out for its AVX-512 lanes by k_pack_groups, up to 24 images at a time) through its own pinned ring
 // and turns them into the byte-exact range-coder stream (NBLIC.c:552-586), while the GPU is already
 // working on the next groups.  The rank's CPU share is what bounds the pipeline, so nothing here spins:
 // drivers sleep on a condition variable, coder threads poll for a chunk with 100 us sleeps.  Three kinds of group: staged -n0 -e1 encode, QNBLIC (effort 0) encode,
@@ -163,7 +163,6 @@ struct ReadyImage {                                                  // everythi
     int kind;                                                        // 0 / 2 = NBLIC range coder, 1 = QNBLIC entropy stage
     ::nblic_amd_batch *batch;                                        // whose completion this image counts towards
     int near, k_step, effort;                                        // header fields (NBLIC.c:682-694)
-    int pack_n, pack_lane;                                           // pack_n > 1: lane pack_lane of a pack of pack_n images whose rows k_mix wrote into pbufs[cb]; 1: on its own, u16 records in cbufs[cb]
 };
 
 // ---- one image in flight -------------------------------------------------------------------
@@ -175,7 +174,6 @@ struct Slot {
     int job = -1, h = 0, w = 0;       // current image
     int near = 0, effort = 1;         // its mode (kind 2 groups; 0 / 1 otherwise)
     uint32_t n_ev = 0;
-    int pack_n = 1, pack_lane = 0;    // its place in a pack of the current launch (launch_back)
     // serial modes: reconstruction (near > 0) and least-squares statistics (efforts 2/3)
     uint8_t *d_recon = nullptr; size_t recon_cap = 0;
     double *d_stats = nullptr; size_t stats_cap = 0;
@@ -239,10 +237,8 @@ struct nblic_amd_ctx {
     int max_take = kMaxTake;                 // images a coder thread takes together: 24 = three AVX-512 packs (NBLIC_AMD_MAX_TAKE=16: two, for A/B runs)
     std::vector<hipStream_t> copy_streams;   // shared by the coder threads (device -> host chunk copies)
     size_t chunk_bins = kChunkBins;          // bins per lane per chunk (NBLIC_AMD_CHUNK_BINS shrinks it, for tests of the chunk boundaries)
-    std::vector<CodedBuf> cbufs;             // one image's u16 records (images coded on their own; QNBLIC: pairs + histograms)
+    std::vector<CodedBuf> cbufs;
     std::deque<int> free_cbufs;
-    std::vector<CodedBuf> pbufs;             // one PACK's rows (eight images' 13-bit groups, written by k_mix); cap in u16 units like cbufs
-    std::deque<int> free_pbufs;
     int coding = 0;                       // images handed to the GPU whose streams are not finished yet
     // coder threads
     std::vector<std::thread> coders;
@@ -383,7 +379,6 @@ static bool launch_front(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs,
         }
         E1Job &J = g.h_jobs[k];
         J.b = s.b; J.h = s.h; J.w = s.w; J.n = uint32_t(n); J.pp = make_plan(J.n); J.n_ev = 0; J.pe = make_plan(0, kTouchSegments);
-        J.near = 0; J.k_step = kMinKStep; J.ktab = 0; J.pack_rows = nullptr; J.pack_lane = 0;
         { static const int dbg = getenv("NBLIC_AMD_DBG") ? atoi(getenv("NBLIC_AMD_DBG")) : 0; J.dbg = dbg; }
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
@@ -417,7 +412,7 @@ static bool launch_front_serial(nblic_amd_ctx *c, Group &g, const uint8_t *const
         if (st) HIP_OK(hipMemsetAsync(s.d_stats, 0, st * sizeof(double), g.stream));         // NBLIC.c:789
         E1Job &J = g.h_jobs[k];
         J.b = s.b; J.h = s.h; J.w = s.w; J.n = uint32_t(n); J.pp = make_plan(J.n); J.n_ev = 0; J.pe = make_plan(0, kTouchSegments); J.dbg = 0;
-        J.near = s.near; J.k_step = k_step_for_near(s.near); J.ktab = level_shift_table(J.k_step); J.pack_rows = nullptr; J.pack_lane = 0;
+        J.near = s.near; J.k_step = k_step_for_near(s.near); J.ktab = level_shift_table(J.k_step);
         SerialJob &Q = g.h_sjobs[k];
         Q = SerialJob{};
         Q.img = s.b.img; Q.recon = want_recon ? s.d_recon : nullptr; Q.rec1 = s.b.rec1; Q.pxs = s.b.pxs; Q.stats = s.d_stats;
@@ -455,29 +450,60 @@ static bool launch_front_serial(nblic_amd_ctx *c, Group &g, const uint8_t *const
 }
 
 // ---- bins leave HBM in the layout the host coder wants ---------------------------------------
-// A host coder thread codes up to 24 images at once: three AVX-512 registers of eight 64-bit lanes in lock-step
-// (range_coder_x8.cpp).  What a register consumes is a PACK: 64 bins of each of its eight lanes as thirteen 64-bit words
-// of 13-bit codes, the eight lanes of a word side by side -- one aligned 64-byte load per four steps.  Rounds 1 and 2
-// let k_mix write one u16 per bin per image and had a second kernel (k_pack_groups) interleave the chunks of whatever
-// images a coder thread had taken, on the coder threads' copy streams: a trivial kernel that averaged 2.5-3.4 ms per
-// call because it queued behind the encoder's kernels, a third of the summed kernel time together with the copies,
-// and -- once the coder threads had stopped being short of CPU -- the slice that separated the line from the device
-// side (round 3: device side alone 7.18 Gpx/s, everything but the coding 6.38, the line 6.37).  Now the pack is fixed
-// when a group is LAUNCHED -- eight consecutive slots of the group are a pack, the slot is the lane -- and k_mix writes
-// the pack's rows itself (kernels_e1.hip): the bins are written once, at 13 bits, no second kernel touches them, and a
-// chunk of a pack is one contiguous copy.  A coder thread takes one to three whole packs.
-// Images that are coded on their own (a group of one, the tail of a batch, a context with the device coder: below)
-// keep the plain u16 records and the scalar coder.
+// A chunk of up to sixteen images becomes ONE contiguous device->host copy of 13-bit groups (range_coder.h,
+// layout in range_coder_x8.cpp): rows[(13 * g + j) * 16 + lane] = word j of the thirteen 64-bit words that hold
+// bins 64g .. 64g+63 of lane `lane` (zero past the lane's end).  On the host a pack's word is one aligned
+// 64-byte load, and the link -- which bounds the pipeline -- carries 13 bits per bin instead of 16.
+// One thread produces one WORD: it reads the four records the word's low 52 bits hold (8 bytes) and the record
+// whose probability rides in its top field (2 bytes; word 12 reads the twelve records whose bins it collects) -- all
+// thirteen threads of a group read inside the same 128-byte line, the sixteen lanes of a word sit side by side, and a
+// wave stores four words x sixteen lanes = 512 contiguous bytes.  No LDS and a handful of registers ON PURPOSE: this
+// kernel runs on the coder threads' streams underneath the encoder's own kernels, and what it costs is the time its
+// workgroups wait for a slot, not its memory efficiency.  (Measured in the pipeline, per 4 Mbin chunk: a thread per
+// group fetching its own 128-byte line 3.5 ms; the same with the lines staged through 33 KB of LDS by coalesced
+// loads 5.9 ms -- the big workgroups find a CU late; the 16-bit interleave this replaces 2.8 ms.)
+// (Measured and rejected: letting this kernel store straight into the mapped host ring.  The
+// PCIe-bound waves crowd the encoder's own kernels off the GPU: 4.6 -> 2.4 Gpx/s.)
+struct InterleaveArgs { const uint16_t *src[kMaxTake]; uint32_t len[kMaxTake]; };
+__global__ void __launch_bounds__(256) k_pack_groups(InterleaveArgs a, uint64_t *__restrict__ rows, uint32_t n_words, uint32_t lanes) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t word = t / lanes, lane = t - word * lanes;   // word = 13 * group + j; lanes = 16 (a pack pair) or 24 (three packs)
+    if (word >= n_words) return;
+    const uint32_t g = word / uint32_t(kGroupWords), j = word - g * uint32_t(kGroupWords);
+    const uint32_t pos = g * uint32_t(kGroupBins), len = a.len[lane];
+    const uint16_t *src = a.src[lane] + pos;                     // chunk starts are multiples of 64 bins in 256-byte aligned buffers
+    auto rec = [&](uint32_t k) { return pos + k < len ? uint64_t(code13(src[k])) : uint64_t(0); };
+    uint64_t v;
+    if (pos + uint32_t(kGroupBins) <= len) {
+        const uint64_t q = *reinterpret_cast<const uint64_t *>(src + 4u * j);
+        v = uint64_t(code13(uint32_t(q) & 0xFFFFu)) | uint64_t(code13(uint32_t(q >> 16) & 0xFFFFu)) << 13 |
+            uint64_t(code13(uint32_t(q >> 32) & 0xFFFFu)) << 26 | uint64_t(code13(uint32_t(q >> 48))) << 39;
+        if (j < 12u) {
+            v |= uint64_t(src[52u + j] & 0xFFFu) << 52;
+        } else {
+            const uint64_t *tail = reinterpret_cast<const uint64_t *>(src + 52);
+            const uint64_t m = 0x8000800080008000ull;
+            // the four bins of each 8-byte load sit at bits 15, 31, 47, 63: gather them to bits 0..3
+            auto bins4 = [&](uint64_t x) { x &= m; return ((x >> 15) | (x >> 30) | (x >> 45) | (x >> 60)) & 0xFull; };
+            v |= (bins4(tail[0]) | bins4(tail[1]) << 4 | bins4(tail[2]) << 8) << 52;
+        }
+    } else {                                                     // the lane's last group of the chunk (or nothing at all)
+        v = rec(4u * j) | rec(4u * j + 1u) << 13 | rec(4u * j + 2u) << 26 | rec(4u * j + 3u) << 39;
+        if (j < 12u) v |= (rec(52u + j) & 0xFFFu) << 52;
+        else for (uint32_t e = 0; e < 12u; e++) v |= (rec(52u + e) >> 12) << (52u + e);
+    }
+    rows[t] = v;
+}
 
-// What a coder thread owns: page-locked rings, so chunk c+1 and c+2 land while chunk c is coded.  Its device->host
-// copies go through one of the context's few copy streams: a stream per thread would outnumber the hardware queues,
-// and streams that share a hardware queue with a group's kernels have their copies stuck behind those kernels.
-constexpr int kPackLanes = 8, kMaxPacks = kMaxTake / kPackLanes;
+// What a coder thread owns: a pinned ring of two half-buffers x sixteen lanes x kChunkBins, so chunk
+// c+1 lands while chunk c is coded.  Its device->host copies go through one of the context's few
+// copy streams: a stream per thread would outnumber the hardware queues, and streams that share a
+// hardware queue with a group's kernels have their copies stuck behind those kernels.
 struct CoderThread {
     hipStream_t stream = nullptr;
     hipEvent_t ev[kRingDepth] = {};
-    uint16_t *ring = nullptr;                            // a lone image's u16 chunks: kRingDepth slots of ring_chunk bins
-    uint64_t *pring = nullptr;                           // packs: kRingDepth slots of kMaxPacks x pring_groups groups x 13 words x 8 lanes
+    uint16_t *ring = nullptr;
+    uint64_t *d_rows = nullptr;                          // device: two halves of 13-bit groups (k_pack_groups' output)
     uint16_t *whole = nullptr; size_t whole_cap = 0;     // pinned; one whole QNBLIC image (its rANS runs last pixel first)
     RangeX8 x8, x8b, x8c;
     RangeScalar x1;
@@ -490,158 +516,153 @@ struct CoderThread {
     }
     void destroy() {
         locked_free(ring);
-        locked_free(reinterpret_cast<uint16_t *>(pring));
         locked_free(whole);
+        if (d_rows) hipFree(d_rows);
         for (auto &e : ev) if (e) hipEventDestroy(e);
     }
-    // The rings are sized by what the thread has actually been asked to code and only grow: a context that codes one
-    // small image through the drop-in entry points pins kilobytes, the bench's threads end up at
-    // 3 slots x 3 packs x 64 Ki groups x 832 B = 491 MB each.
-    size_t ring_chunk = 0, pring_groups = 0;
-    bool ensure_ring(size_t chunk) {
+    // The ring holds kRingDepth slots of ring_lanes x ring_chunk bins; it is sized by what the thread has actually been
+    // asked to code (one lane for an image coded alone, sixteen for a pack pair; the chunk no longer than the longest
+    // image) and only grows: a context that codes one small image through the drop-in entry points pins kilobytes,
+    // the bench's threads end up at 3 x 24 x 4 Mbin x 1.625 B = 491 MB each.
+    size_t ring_lanes = 0, ring_chunk = 0, rows_cap = 0;
+    // 16-bit words per ring slot: a lone image's chunk as it is, or the 13-bit groups of ring_lanes lanes
+    size_t slot_words() const { return ring_lanes > 1 ? group_words(ring_chunk, ring_lanes) * 4 : ring_chunk; }
+    bool ensure_ring(size_t lanes, size_t chunk, bool need_rows) {
         chunk = (chunk + 4095) & ~size_t(4095);
-        if (chunk > ring_chunk) {
+        if (lanes > ring_lanes || chunk > ring_chunk) {
+            const size_t nl = lanes > ring_lanes ? lanes : ring_lanes, nc = chunk > ring_chunk ? chunk : ring_chunk;
             locked_free(ring);
-            ring_chunk = chunk;
-            ring = locked_alloc(kRingDepth * ring_chunk);
-            if (!ring) { ring_chunk = 0; fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
+            ring_lanes = nl; ring_chunk = nc;
+            ring = locked_alloc(kRingDepth * slot_words());
+            if (!ring) { ring_lanes = ring_chunk = 0; fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's ring\n"); return false; }
+        }
+        const size_t want_rows = need_rows ? kRingDepth * group_words(ring_chunk, ring_lanes) : 0;
+        if (want_rows > rows_cap) {
+            if (d_rows) hipFree(d_rows);
+            d_rows = nullptr; rows_cap = 0;
+            HIP_OK(hipMalloc((void **)&d_rows, want_rows * sizeof(uint64_t)));
+            rows_cap = want_rows;
         }
         return true;
     }
-    size_t pack_slot_words() const { return size_t(kMaxPacks) * pring_groups * kGroupWords * kPackLanes; }
-    bool ensure_pack_ring(size_t groups) {
-        groups = (groups + 63) & ~size_t(63);
-        if (groups > pring_groups) {
-            locked_free(reinterpret_cast<uint16_t *>(pring));
-            pring_groups = groups;
-            pring = reinterpret_cast<uint64_t *>(locked_alloc(kRingDepth * pack_slot_words() * 4));
-            if (!pring) { pring_groups = 0; fprintf(stderr, "[nblic_amd] cannot allocate the coder thread's pack ring\n"); return false; }
-        }
-        return true;
-    }
-    uint16_t *slot(size_t chunk) { return ring + size_t(chunk % kRingDepth) * ring_chunk; }
-    uint64_t *pack_rows(size_t chunk, int pack) { return pring + size_t(chunk % kRingDepth) * pack_slot_words() + size_t(pack) * pring_groups * kGroupWords * kPackLanes; }
+    uint16_t *slot(size_t chunk) { return ring + size_t(chunk % kRingDepth) * slot_words(); }            // a lone image's chunk
+    uint64_t *rows(size_t chunk) { return reinterpret_cast<uint64_t *>(slot(chunk)); }
+    uint64_t *dev_rows(size_t chunk) { return d_rows + size_t(chunk % kRingDepth) * group_words(ring_chunk, ring_lanes); }
 };
 
-// a sleeping poll: hipEventSynchronize spins through the wait (see GroupWait), and CPU time is what the rank is
-// short of; a chunk is ~30 ms of coding, so 100 us of extra latency on its arrival is nothing.
-// (Measured and rejected: sleeping on a condition variable woken by a host function behind the copy, as the
-// driver threads do.  A host function holds its stream until it has run, two threads share a copy stream,
-// and the chunks arrived so much later that the threads fell back to packs of eight: 6.1 -> 4.0 Gpx/s.)
-static bool wait_chunk(CoderThread &t, hipEvent_t e) {
-    const auto w0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t q = hipEventQuery(e);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) { fprintf(stderr, "[nblic_amd] HIP error: %s\n", hipGetErrorString(q)); return false; }
-        std::this_thread::sleep_for(std::chrono::microseconds(100));
-    }
-    t.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-    return true;
-}
-
-// One image on its own: its u16 records stream from HBM chunk by chunk into the scalar coder.  len = coder bytes or SIZE_MAX.
-static bool code_single(CoderThread &t, const uint16_t *dev, size_t n, uint8_t *dst, size_t cap, size_t *len, size_t chunk_bins) {
-    if (!t.ensure_ring(n < chunk_bins ? n + 4 : chunk_bins)) return false;
-    const size_t chunks = (n + chunk_bins - 1) / chunk_bins;
-    auto chunk_len = [&](size_t c) { const size_t off = c * chunk_bins; return off >= n ? size_t(0) : (n - off < chunk_bins ? n - off : chunk_bins); };
+// Streams `take` images' bins from HBM and codes them: one image with the scalar coder, up to
+// eight in the lanes of the AVX-512 coder, up to sixteen as two packs in lock-step.
+// lens[k] = coder bytes or SIZE_MAX.
+static bool code_streamed(CoderThread &t, const uint16_t *const *dev, const size_t *n, int take, uint8_t *const *dst,
+                          const size_t *caps, size_t *lens, size_t chunk_bins) {
+    size_t n_max = 0;
+    for (int k = 0; k < take; k++) n_max = n[k] > n_max ? n[k] : n_max;
+    // More than one image: AVX-512 packs in lock-step -- a lone pack is bound by the latency of its own dependent
+    // chain, a second one rides along almost for free, a third on what the core's ports have left (+20 % bins per
+    // CPU-second on the records of real frames, and the rank's CPU quota is what bounds the pipeline).  Up to sixteen
+    // images make two packs (16 lanes per word-row), more make three (24 lanes); the images are dealt to the packs
+    // in order, as evenly as they go: pack p owns lanes 8p .. 8p + count_p - 1.
+    const int n_packs = take > 16 ? 3 : (take > 1 ? 2 : 0);
+    const size_t lanes = size_t(8 * n_packs);
+    int pack_n[3] = {0, 0, 0}, pack_first[3] = {0, 0, 0};
+    for (int p = 0, at = 0; p < n_packs; p++) { pack_n[p] = take / n_packs + (p < take % n_packs ? 1 : 0); pack_first[p] = at; at += pack_n[p]; }
+    if (!t.ensure_ring(take > 1 ? lanes : 1, n_max < chunk_bins ? n_max + 4 : chunk_bins, take > 1)) return false;
+    const size_t chunks = (n_max + chunk_bins - 1) / chunk_bins;                     // chunk_bins <= kChunkBins, the ring's slot size
+    auto chunk_len = [&](size_t c, int k) { const size_t off = c * chunk_bins; return off >= n[k] ? size_t(0) : (n[k] - off < chunk_bins ? n[k] - off : chunk_bins); };
+    auto lane_of = [&](int k) { int p = 0; while (p + 1 < n_packs && k >= pack_first[p + 1]) p++; return 8 * p + (k - pack_first[p]); };
     auto issue = [&](size_t c) -> bool {
-        HIP_OK(hipMemcpyAsync(t.slot(c), dev + c * chunk_bins, chunk_len(c) * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
-        HIP_OK(hipEventRecord(t.ev[c % kRingDepth], t.stream));
-        return true;
-    };
-    t.x1.begin(dst, cap);
-    for (size_t c = 0; c + 1 < size_t(kRingDepth) && c < chunks; c++) if (!issue(c)) return false;
-    for (size_t c = 0; c < chunks; c++) {
-        const auto i0 = std::chrono::steady_clock::now();
-        if (c + kRingDepth - 1 < chunks && !issue(c + kRingDepth - 1)) return false;      // its ring slot was consumed one chunk ago
-        t.issue_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
-        if (!wait_chunk(t, t.ev[c % kRingDepth])) return false;
-        t.x1.feed(t.slot(c), chunk_len(c));
-    }
-    *len = t.x1.finish();
-    return true;
-}
-
-// One to three PACKS (k_mix wrote their rows): chunk by chunk -- a contiguous copy per pack -- through the AVX-512
-// coders in lock-step.  n[8 p + lane] = bins of the image in lane `lane` of pack p (0 = no image); lens likewise.
-static bool code_packs(CoderThread &t, int n_packs, const uint64_t *const *dev_rows, const int *pack_n, const size_t *n, uint8_t *const *dst,
-                       const size_t *caps, size_t *lens, size_t chunk_bins) {
-    size_t groups[kMaxPacks] = {0, 0, 0}, most = 0;
-    for (int p = 0; p < n_packs; p++) {
-        for (int k = 0; k < pack_n[p]; k++) groups[p] = std::max(groups[p], (n[kPackLanes * p + k] + kGroupBins - 1) / kGroupBins);
-        most = std::max(most, groups[p]);
-    }
-    const size_t chunk_groups = std::min(chunk_bins / kGroupBins, most ? most : size_t(1));
-    if (!t.ensure_pack_ring(chunk_groups)) return false;
-    const size_t chunks = (most + chunk_groups - 1) / chunk_groups;
-    static const int feed_dbg = getenv("NBLIC_AMD_DBG") ? atoi(getenv("NBLIC_AMD_DBG")) : 0;      // measurement aids: & 128 bins reach the host but are not coded, & 1024 (with 128) no copy either
-    auto issue = [&](size_t c) -> bool {
-        for (int p = 0; p < n_packs; p++) {
-            const size_t g0 = c * chunk_groups;
-            if (g0 >= groups[p]) continue;
-            const size_t gl = std::min(chunk_groups, groups[p] - g0);
-            // (In this pipeline the runtime performs the copies with its blit kernel whatever was tried -- ring from hipHostMalloc
-            // instead of hipHostRegister, 2 / 4 / 8 copy streams, smaller pieces; with /opt/rocm's runtime they go through SDMA,
-            // and the line is the same or lower: 6.14-6.21 against 6.25-6.35 Gpx/s, round 3.  DESIGN.md section 4.)
-            if (!(feed_dbg & 1024)) HIP_OK(hipMemcpyAsync(t.pack_rows(c, p), dev_rows[p] + g0 * kGroupWords * kPackLanes, gl * kGroupWords * kPackLanes * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
-        }
-        HIP_OK(hipEventRecord(t.ev[c % kRingDepth], t.stream));
-        return true;
-    };
-    RangeX8 *const packs[kMaxPacks] = {&t.x8, &t.x8b, &t.x8c};
-    for (int p = 0; p < n_packs; p++) packs[p]->begin(pack_n[p], dst + kPackLanes * p, caps + kPackLanes * p);
-    for (size_t c = 0; c + 1 < size_t(kRingDepth) && c < chunks; c++) if (!issue(c)) return false;
-    const size_t chunk = chunk_groups * kGroupBins;
-    for (size_t c = 0; c < chunks; c++) {
-        const auto i0 = std::chrono::steady_clock::now();
-        if (c + kRingDepth - 1 < chunks && !issue(c + kRingDepth - 1)) return false;      // its ring slot was consumed one chunk ago
-        t.issue_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
-        if (!wait_chunk(t, t.ev[c % kRingDepth])) return false;
-        size_t len[kMaxTake] = {0};
-        const uint64_t *rows_p[kMaxPacks] = {nullptr, nullptr, nullptr};
-        for (int p = 0; p < n_packs; p++) {
-            rows_p[p] = t.pack_rows(c, p);
-            for (int k = 0; k < pack_n[p]; k++) {
-                const size_t all = n[kPackLanes * p + k], off = c * chunk;
-                len[kPackLanes * p + k] = off >= all ? 0 : std::min(chunk, all - off);
+        if (take == 1) {                                      // one image: its bins as they are, for the scalar coder
+            HIP_OK(hipMemcpyAsync(t.slot(c), dev[0] + c * chunk_bins, chunk_len(c, 0) * sizeof(uint16_t), hipMemcpyDeviceToHost, t.stream));
+        } else {                                              // a pack pair: interleaved on the GPU, one copy
+            InterleaveArgs a{};
+            size_t longest = 0;
+            for (int k = 0; k < take; k++) {
+                const size_t len = chunk_len(c, k);
+                a.src[lane_of(k)] = dev[k] + c * chunk_bins; a.len[lane_of(k)] = uint32_t(len);
+                longest = len > longest ? len : longest;
+            }
+            const uint32_t n_groups = uint32_t((longest + kGroupBins - 1) / kGroupBins);
+            // (Measured and rejected, twice: letting this kernel store straight into the mapped host ring.  Round 1, chip-wide
+            // grid: 4.6 -> 2.4 Gpx/s.  Round 2, small grids so that few CUs wait on the link: 3.34 / 2.68 / 2.46 Gpx/s with
+            // 16 / 48 / 128 workgroups per chunk against 5.5 with the staging pass + runtime copy.)
+            uint64_t *d = t.dev_rows(c);
+            static const int feed_dbg = getenv("NBLIC_AMD_DBG") ? atoi(getenv("NBLIC_AMD_DBG")) : 0;      // measurement aids (with & 128): & 512 no pack kernel, & 1024 no copy
+            if (n_groups) {
+                if (!(feed_dbg & 512)) hipLaunchKernelGGL(k_pack_groups, dim3((n_groups * uint32_t(kGroupWords) * uint32_t(lanes) + 255u) / 256u), dim3(256), 0, t.stream, a, d, n_groups * uint32_t(kGroupWords), uint32_t(lanes));
+                HIP_OK(hipGetLastError());
+                // (In this pipeline the runtime performs the copy with its blit kernel -- four 32 MB dispatches per 128 MB chunk --
+                // whatever was tried: ring from hipHostMalloc instead of hipHostRegister, 2 / 4 / 8 copy streams, the copy cut
+                // into 8 or 16 MB pieces; the same copy from a bare test program goes through SDMA.  DESIGN.md section 4.)
+                if (!(feed_dbg & 1024)) HIP_OK(hipMemcpyAsync(t.rows(c), d, group_words(longest, lanes) * sizeof(uint64_t), hipMemcpyDeviceToHost, t.stream));
             }
         }
-        if (!(feed_dbg & 128)) feed_packs(packs, n_packs, rows_p, len);
+        // (Measured and rejected: sleeping on a condition variable woken by a host function behind the copy, as the
+        // driver threads do.  A host function holds its stream until it has run, two threads share a copy stream,
+        // and the chunks arrived so much later that the threads fell back to packs of eight: 6.1 -> 4.0 Gpx/s.
+        // The threads wait for chunks for < 10 % of their time, so what the event wait burns is small.)
+        HIP_OK(hipEventRecord(t.ev[c % kRingDepth], t.stream));
+        return true;
+    };
+    RangeX8 *const packs[3] = {&t.x8, &t.x8b, &t.x8c};
+    if (take > 1) { for (int p = 0; p < n_packs; p++) packs[p]->begin(pack_n[p], dst + pack_first[p], caps + pack_first[p]); }
+    else t.x1.begin(dst[0], caps[0]);
+    for (size_t c = 0; c + 1 < size_t(kRingDepth) && c < chunks; c++) if (!issue(c)) return false;
+    for (size_t c = 0; c < chunks; c++) {
+        auto i0 = std::chrono::steady_clock::now();
+        if (c + kRingDepth - 1 < chunks && !issue(c + kRingDepth - 1)) return false;      // its ring slot was consumed one chunk ago
+        auto w0 = std::chrono::steady_clock::now();
+        t.issue_s += std::chrono::duration<double>(w0 - i0).count();
+        // a sleeping poll: hipEventSynchronize spins through the wait (see GroupWait), and CPU time is what the rank is
+        // short of; a chunk is ~30 ms of coding, so 100 us of extra latency on its arrival is nothing
+        for (;;) {
+            const hipError_t q = hipEventQuery(t.ev[c % kRingDepth]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { fprintf(stderr, "[nblic_amd] HIP error: %s\n", hipGetErrorString(q)); return false; }
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+        t.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+        if (take > 1) {
+            size_t len[kMaxTake] = {0};
+            for (int k = 0; k < take; k++) len[lane_of(k)] = chunk_len(c, k);
+            static const bool feed_only = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 128);   // measurement aid: bins reach the host but are not coded
+            if (feed_only) {}
+            else if (n_packs == 3) feed_triple_groups(t.x8, t.x8b, t.x8c, t.rows(c), len);
+            else feed_pair_groups(t.x8, t.x8b, t.rows(c), len);
+        } else {
+            t.x1.feed(t.slot(c), chunk_len(c, 0));
+        }
     }
-    for (int p = 0; p < n_packs; p++) packs[p]->end(lens + kPackLanes * p);
+    if (take > 1) { for (int p = 0; p < n_packs; p++) packs[p]->end(lens + pack_first[p]); }
+    else lens[0] = t.x1.finish();
     return true;
 }
 
-// Coder thread.  Measured on the GPU box (EPYC 9575F), per thread: one stream alone 400-510 Mbins/s; one pack of eight
-// 1300, two packs in lock-step 1950-2000, three 2200-2400 -- at 2.5x / 3.4x the latency of a stream coded alone.  What a
-// thread takes:
-//   a pack at the front of the queue: as many whole packs as are there, up to three; mid-batch, with every other thread
-//       busy, it waits the ~30-45 ms it takes for three to be queued (two while others are idle too: a lone pack costs
-//       twice the CPU time per bin);
-//   an image on its own: that image (the scalar coder).  Whether an image is packed is decided when its group is
-//       launched (launch_back): towards the end of a batch -- at most two images per thread left -- and in groups of one
-//       every image goes to a thread of its own, which is what makes a short batch fast.
-// (Alternatives ranked with a discrete-event model of arrivals and coder speeds, tools/coder_policy_sim.py, then in situ.)
-static int coder_take(const nblic_amd_ctx *c) {                  // call with c->rm held; 0 = nothing to take; else the number of IMAGES
+// Coder thread.  Measured on the GPU box (EPYC 9575F), per thread: one stream alone 400-510
+// Mbins/s; packs always run as two AVX-512 registers in lock-step: 2 x 4 images 1300 Mbins/s,
+// 2 x 8 images 1950 Mbins/s -- at 2.5x / 3.4x the latency of a stream coded alone.  The host's
+// CPU share (16 cores, enforced as a quota), not the GPU, bounds the pipeline, so what counts is
+// bins per CPU-second: mid-batch, once every other thread is busy, a thread waits the ~30 ms it
+// takes for sixteen images to be queued rather than start a smaller pack (while others are idle --
+// the start of a batch -- it takes what is there, so all threads are at work within 0.4 s);
+// towards the end it takes whatever is there; and only
+// when at most two images per thread are left -- a short batch, or the very tail of a long one --
+// does each image go to a thread of its own.  (Alternatives ranked with a
+// discrete-event model of arrivals and coder speeds, tools/coder_policy_sim.py, then in situ.)
+static int coder_take(const nblic_amd_ctx *c) {                  // call with c->rm held; 0 = nothing to take
     const size_t q = c->ready.size();
     if (q == 0) return 0;
-    const ReadyImage &f = c->ready.front();
-    if (f.kind == 1 || f.pack_n <= 1) return 1;
-    const int max_packs = std::max(1, c->max_take / kPackLanes);
-    int packs = 0; size_t imgs = 0;
-    bool more_may_join = true;                                   // false: something that is not a pack follows the packs at the front
-    for (size_t i = 0; i < q && packs < max_packs;) {            // whole packs at the front (a pack is queued in one piece, lane 0 first)
-        const ReadyImage &r = c->ready[i];
-        if (r.kind == 1 || r.pack_n <= 1) { more_may_join = false; break; }
-        imgs += size_t(r.pack_n); i += size_t(r.pack_n); packs++;
-    }
+    if (c->ready.front().kind == 1 || !c->simd) return 1;
     const size_t left = q + size_t(c->batch_to_come), threads = c->coders.size();
-    if (more_may_join && c->batch_to_come > 0 && left >= 4 * threads) {
-        const int want = c->idle_coders <= 1 ? max_packs : std::min(max_packs, 2);
-        if (packs < want) return 0;
+    if (left <= 2 * threads) return 1;                           // two rounds of singles beat one small pack
+    const size_t full = size_t(c->max_take);
+    if (c->batch_to_come > 0 && left >= 4 * threads) {
+        // mid-batch: with every other thread busy wait (~30-45 ms) for a full set; with others idle too -- the start of a
+        // batch, or the GPU side not keeping up -- at least for two full packs: packs of four lanes cost twice the CPU
+        // time per bin, and CPU time is what the rank is short of
+        const size_t want = c->idle_coders <= 1 ? full : (full < 16 ? full : size_t(16));
+        if (q < want) return 0;
     }
-    return int(imgs);
+    return int(q < full ? q : full);
 }
 
 // One logical CPU per physical core of the process's affinity mask (the lowest-numbered sibling that is allowed).
@@ -729,44 +750,31 @@ static void coder_main(nblic_amd_ctx *c, int index) {
         }
         auto t0 = std::chrono::steady_clock::now();
         if (c->trace) fprintf(stderr, "[trace] %.3f coder %d takes %d\n", c->now(), index, take);
-        size_t n[kMaxTake] = {0}, caps[kMaxTake] = {0}, lens[kMaxTake]; uint8_t *dst[kMaxTake] = {nullptr};
-        int at[kMaxTake];                                        // image k of the take sits in lane at[k] of the arrays above (8 p + lane for packs)
-        const uint64_t *rows[kMaxPacks] = {nullptr, nullptr, nullptr}; int pack_n[kMaxPacks] = {0, 0, 0};
-        int n_packs = 0;
+        const uint16_t *src[kMaxTake]; size_t n[kMaxTake], caps[kMaxTake], lens[kMaxTake]; uint8_t *dst[kMaxTake];
         double bins = 0;
         for (int k = 0; k < take; k++) {
-            if (im[k].pack_n > 1 && im[k].pack_lane == 0) { rows[n_packs] = reinterpret_cast<const uint64_t *>(c->pbufs[size_t(im[k].cb)].p); pack_n[n_packs] = im[k].pack_n; n_packs++; }
-            at[k] = im[k].pack_n > 1 ? kPackLanes * (n_packs - 1) + im[k].pack_lane : 0;
+            src[k] = c->cbufs[size_t(im[k].cb)].p; n[k] = im[k].n_ev; bins += double(im[k].n_ev);
             const size_t cap = im[k].caps[im[k].job] < (size_t(1) << 46) ? im[k].caps[im[k].job] : (size_t(1) << 46);   // SIZE_MAX = "no limit"
-            n[at[k]] = im[k].n_ev; bins += double(im[k].n_ev);
-            dst[at[k]] = im[k].outs[im[k].job] + kHeaderBytes;
-            caps[at[k]] = cap >= size_t(kHeaderBytes) ? cap - kHeaderBytes : 0;
+            dst[k] = im[k].outs[im[k].job] + kHeaderBytes;
+            caps[k] = cap >= size_t(kHeaderBytes) ? cap - kHeaderBytes : 0;
             if (cap >= size_t(kHeaderBytes)) write_header(im[k].outs[im[k].job], im[k].h, im[k].w, im[k].near, im[k].k_step, im[k].effort);
         }
         static const bool skip_coding = getenv("NBLIC_AMD_DBG") && (atoi(getenv("NBLIC_AMD_DBG")) & 16);   // measurement aid: device side alone
-        bool ok = true;
-        if (skip_coding) { for (int k = 0; k < take; k++) lens[at[k]] = 0; }
-        else if (n_packs > 0) ok = code_packs(t, n_packs, rows, pack_n, n, dst, caps, lens, c->chunk_bins);
-        else ok = code_single(t, c->cbufs[size_t(im[0].cb)].p, n[0], dst[0], caps[0], &lens[0], c->chunk_bins);
-        if (!ok) {
+        if (skip_coding) { for (int k = 0; k < take; k++) lens[k] = 0; }
+        else if (!code_streamed(t, src, n, take, dst, caps, lens, c->chunk_bins)) {
             hipDeviceSynchronize();
-            for (int k = 0; k < take; k++) lens[at[k]] = SIZE_MAX;
+            for (int k = 0; k < take; k++) lens[k] = SIZE_MAX;
         }
         for (int k = 0; k < take; k++) {
-            const size_t l = lens[at[k]];
-            if (l == SIZE_MAX) fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", im[k].job, im[k].caps[im[k].job]);
-            im[k].lens[im[k].job] = l == SIZE_MAX ? -1 : long(kHeaderBytes + l);
+            if (lens[k] == SIZE_MAX) fprintf(stderr, "[nblic_amd] image %d: output buffer of %zu bytes is too small\n", im[k].job, im[k].caps[im[k].job]);
+            im[k].lens[im[k].job] = lens[k] == SIZE_MAX ? -1 : long(kHeaderBytes + lens[k]);
         }
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (c->trace) fprintf(stderr, "[trace] %.3f coder %d finished %d in %.3f s\n", c->now(), index, take, dt);
         { std::lock_guard<std::mutex> l(c->stat_m); c->total_bins += bins; c->coder_s += dt; if (take > 1) { c->pack_bins += bins; c->pack_s += dt; } c->wait_s += t.wait_s; t.wait_s = 0; c->issue_s += t.issue_s; t.issue_s = 0; c->takes[take]++; }
         {
             std::lock_guard<std::mutex> l(c->fm);
-            for (int k = 0; k < take; k++) {
-                if (im[k].pack_n <= 1) c->free_cbufs.push_back(im[k].cb);
-                else if (im[k].pack_lane == 0) c->free_pbufs.push_back(im[k].cb);      // the pack's rows go back once
-                if (im[k].batch) im[k].batch->remaining -= 1;
-            }
+            for (int k = 0; k < take; k++) { c->free_cbufs.push_back(im[k].cb); if (im[k].batch) im[k].batch->remaining -= 1; }
             c->coding -= take;
         }
         c->fcv.notify_all();
@@ -784,10 +792,10 @@ constexpr int kDevPack = 64;
 
 static int dev_take(const nblic_amd_ctx *c) {                  // call with c->rm held
     const size_t q = c->ready.size();
-    const size_t reserve = c->coders.size();                     // (with the device coder on, every image is coded on its own: launch_back)
+    const size_t reserve = c->simd ? c->coders.size() * size_t(kMaxTake) / 2 : c->coders.size();
     if (q < size_t(kDevPack) + reserve) return 0;
     if (int(q) + c->batch_to_come + c->queued_images < c->dev_min_outstanding) return 0;
-    for (size_t k = 0; k < size_t(kDevPack); k++) if (c->ready[q - 1 - k].kind == 1 || c->ready[q - 1 - k].pack_n > 1) return 0;   // QNBLIC images and packs are host work
+    for (size_t k = 0; k < size_t(kDevPack); k++) if (c->ready[q - 1 - k].kind == 1) return 0;   // QNBLIC images are host work
     return kDevPack;
 }
 
@@ -881,25 +889,6 @@ static bool acquire_coded(nblic_amd_ctx *c, Slot &s, size_t words) {
     return true;
 }
 
-// Takes a buffer for the rows of one pack whose longest image has `max_ev` bins (13 words x 8 lanes per 64 bins).
-static bool acquire_pack(nblic_amd_ctx *c, int *id, size_t max_ev) {
-    {
-        std::unique_lock<std::mutex> l(c->fm);
-        c->fcv.wait(l, [c] { return !c->free_pbufs.empty(); });
-        *id = c->free_pbufs.front(); c->free_pbufs.pop_front();
-    }
-    CodedBuf &pb = c->pbufs[size_t(*id)];
-    const size_t words = ((max_ev + kGroupBins - 1) / kGroupBins + 1) * kGroupWords * kPackLanes * 4;      // in u16 units, like CodedBuf::cap
-    if (pb.cap < words) {
-        if (pb.p) hipFree(pb.p);
-        pb.p = nullptr; pb.cap = 0;
-        const size_t cap = words + words / 16 + 4096;
-        HIP_OK(hipMalloc((void **)&pb.p, cap * sizeof(uint16_t)));
-        pb.cap = cap;
-    }
-    return true;
-}
-
 // Runs on a HIP runtime thread when the group's kernels have finished: queues the images for the
 // coder threads and hands the device workspace back.  (No HIP calls in here.)
 static void on_group_done(void *vp) {
@@ -910,7 +899,7 @@ static void on_group_done(void *vp) {
         std::lock_guard<std::mutex> l(c->rm);
         for (int k = 0; k < gp->n_jobs; k++) {
             const Slot &s = gp->slots[size_t(k)];
-            c->ready.push_back(ReadyImage{s.cb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens, gp->kind, gp->batch, s.near, k_step_for_near(s.near), s.effort, s.pack_n, s.pack_lane});
+            c->ready.push_back(ReadyImage{s.cb, s.job, s.h, s.w, s.n_ev, gp->outs, gp->caps, gp->lens, gp->kind, gp->batch, s.near, k_step_for_near(s.near), s.effort});
         }
         c->batch_to_come -= gp->n_jobs;
     }
@@ -942,42 +931,13 @@ static bool launch_back(nblic_amd_ctx *c, Group &g, bool with_coders, bool gener
     for (int k = 0; k < g.n_jobs; k++) {
         Slot &s = g.slots[size_t(k)];
         s.n_ev = g.h_totals[size_t(k) * kTotalsStride + 2];
-        s.pack_n = 1; s.pack_lane = 0;
         if (s.n_ev >= 0x7FFFFFFFu) { fprintf(stderr, "[nblic_amd] event count overflow\n"); return false; }
         if (!ensure_events(s, s.n_ev)) return false;
-    }
-    // Packs: eight consecutive slots of the launch are coded together by one AVX-512 register of a coder thread, and k_mix
-    // writes their rows (kernels_e1.h E1Job::pack_rows).  Not packed: a slot on its own; everything while at most two images
-    // per coder thread are outstanding (the tail of a batch, a short batch: an image per thread finishes sooner than a
-    // pack per thread); hosts without AVX-512; a context whose device coder is on (it takes single images' u16 records).
-    bool packing = with_coders && c->simd && g.n_jobs >= 2 && c->dev_coders.empty();
-    if (packing) {
-        std::lock_guard<std::mutex> l(c->rm);
-        packing = c->ready.size() + size_t(c->batch_to_come) + size_t(c->queued_images) > 2 * c->coders.size();
-    }
-    for (int k0 = 0; k0 < g.n_jobs; k0 += kPackLanes) {
-        const int cnt = std::min(kPackLanes, g.n_jobs - k0);
-        int pack_id = -1;
-        if (packing && cnt >= 2) {
-            size_t max_ev = 0;
-            for (int k = k0; k < k0 + cnt; k++) max_ev = std::max(max_ev, size_t(g.slots[size_t(k)].n_ev));
-            if (!acquire_pack(c, &pack_id, max_ev)) return false;
-        }
-        for (int k = k0; k < k0 + cnt; k++) {
-            Slot &s = g.slots[size_t(k)];
-            E1Job &J = g.h_jobs[k];
-            if (pack_id >= 0) {
-                s.cb = pack_id; s.pack_n = cnt; s.pack_lane = k - k0;
-                s.b.coded = nullptr;
-                J.pack_rows = reinterpret_cast<uint64_t *>(c->pbufs[size_t(pack_id)].p); J.pack_lane = s.pack_lane;
-            } else {
-                // the coded bins go straight into a pool buffer that outlives this group's turn on the slot
-                if (!acquire_coded(c, s, size_t(s.n_ev) + 8)) return false;
-                s.b.coded = c->cbufs[size_t(s.cb)].p;
-                J.pack_rows = nullptr; J.pack_lane = 0;
-            }
-            J.b = s.b; J.n_ev = s.n_ev; J.pe = make_plan(s.n_ev, kTouchSegments);
-        }
+        // the coded bins go straight into a pool buffer that outlives this group's turn on the slot
+        if (!acquire_coded(c, s, size_t(s.n_ev) + 8)) return false;
+        s.b.coded = c->cbufs[size_t(s.cb)].p;
+        E1Job &J = g.h_jobs[k];
+        J.b = s.b; J.n_ev = s.n_ev; J.pe = make_plan(s.n_ev, kTouchSegments);
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
     e1_launch_back(g.d_jobs, g.h_jobs, g.n_jobs, g.stream, (c->timing && !general) ? &g.tm : nullptr, general);
@@ -1034,9 +994,7 @@ static void driver_main(nblic_amd_ctx *c, int id) {
                 std::lock_guard<std::mutex> l(c->fm);
                 for (int k = 0; k < g.n_jobs; k++) {
                     Slot &s = g.slots[size_t(k)];
-                    if (s.cb >= 0 && s.pack_n <= 1) c->free_cbufs.push_back(s.cb);
-                    else if (s.cb >= 0 && s.pack_lane == 0) c->free_pbufs.push_back(s.cb);
-                    s.cb = -1; s.pack_n = 1; s.pack_lane = 0;
+                    if (s.cb >= 0) { c->free_cbufs.push_back(s.cb); s.cb = -1; }
                 }
             }
             { std::lock_guard<std::mutex> l(c->rm); c->batch_to_come -= g.n_jobs; }
@@ -1108,7 +1066,7 @@ static void encode_submit(nblic_amd_ctx *c, nblic_amd_batch *b, int n_images, co
         while (next < order.size() && g.n_jobs < int(g.slots.size()) && (class_of(order[next]) == 0 ? 0 : 2) == kind) {
             const int k = order[next++];
             Slot &s = g.slots[size_t(g.n_jobs++)];
-            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1; s.pack_n = 1; s.pack_lane = 0; s.near = near_of(k); s.effort = effort_of(k);
+            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1; s.near = near_of(k); s.effort = effort_of(k);
             if (kind == 0 && recons && recons[k]) {                       // -n0 -e1: the reconstruction IS the input (NBLIC.c:876 rewrites the same bytes)
                 const size_t n = size_t(hs[k]) * size_t(ws[k]);
                 if (on_device) { if (hipMemcpy(recons[k], imgs[k], n, hipMemcpyDeviceToHost) != hipSuccess) b->ok = false; }
@@ -1203,7 +1161,6 @@ static bool launch_q(nblic_amd_ctx *c, Group &g, const uint8_t *const *imgs, boo
         }
         E1Job &J = g.h_jobs[k];
         J.b = s.b; J.h = s.h; J.w = s.w; J.n = uint32_t(n); J.pp = make_plan(J.n); J.n_ev = 0; J.pe = make_plan(0, kTouchSegments); J.dbg = 0;
-        J.pack_rows = nullptr; J.pack_lane = 0;
         s.n_ev = 0;
     }
     HIP_OK(hipMemcpyAsync(g.d_jobs, g.h_jobs, size_t(g.n_jobs) * sizeof(E1Job), hipMemcpyHostToDevice, g.stream));
@@ -1243,7 +1200,7 @@ static bool encode_q_batch(nblic_amd_ctx *c, int n_images, const uint8_t *const 
             int k = next++;
             if (!size_ok(hs[k], ws[k], c->max_px)) { ok = false; std::lock_guard<std::mutex> l(c->rm); c->batch_to_come--; continue; }
             Slot &s = g.slots[size_t(g.n_jobs++)];
-            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1; s.pack_n = 1; s.pack_lane = 0; s.near = 0; s.effort = 1;
+            s.job = k; s.h = hs[k]; s.w = ws[k]; s.cb = -1; s.near = 0; s.effort = 1;
         }
         if (g.n_jobs == 0) { release_group(c, id); continue; }
         start_group(c, g, imgs, on_device);
@@ -1850,9 +1807,6 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     }
     c->cbufs.resize(size_t(n_host_buffers));
     for (int i = 0; i < n_host_buffers; i++) c->free_cbufs.push_back(i);
-    const int n_packs = std::max(4, n_host_buffers / kPackLanes + 2);       // the same backlog, counted in packs of eight images
-    c->pbufs.resize(size_t(n_packs));
-    for (int i = 0; i < n_packs; i++) c->free_pbufs.push_back(i);
     if (hipStreamCreateWithFlags(&c->dec_stream, hipStreamNonBlocking) != hipSuccess) { c->dec_stream = nullptr; nblic_amd_destroy(c); return nullptr; }
     // (Measured and rejected: creating the copy streams with the highest stream priority, so that the
     // coder threads' short interleave kernels and copies overtake the encoder's long kernels -- the
@@ -1897,7 +1851,6 @@ void nblic_amd_destroy(nblic_amd_ctx *c) {
     for (auto &t : c->drivers) t.join();
     for (auto &g : c->groups) group_free(g);
     for (auto &cb : c->cbufs) if (cb.p) hipFree(cb.p);
-    for (auto &pb : c->pbufs) if (pb.p) hipFree(pb.p);
     for (auto &cs : c->copy_streams) if (cs) hipStreamDestroy(cs);
     hipFree(c->dec_arena); hipFree(c->dec_jobs);
     if (c->feed_pipe[0] >= 0) { close(c->feed_pipe[0]); close(c->feed_pipe[1]); }
@@ -1974,7 +1927,7 @@ long nblic_amd_debug_stage(nblic_amd_ctx *c, const unsigned char *img, int h, in
     { std::unique_lock<std::mutex> l(c->fm); c->fcv.wait(l, [c] { return !c->free_groups.empty(); }); id = c->free_groups.front(); c->free_groups.pop_front(); }
     Group &grp = c->groups[size_t(id)];
     Slot &s = grp.slots[0];
-    grp.n_jobs = 1; s.job = 0; s.h = h; s.w = w; s.cb = -1; s.pack_n = 1; s.pack_lane = 0; s.near = 0; s.effort = 1;
+    grp.n_jobs = 1; s.job = 0; s.h = h; s.w = w; s.cb = -1; s.near = 0; s.effort = 1;
     const uint8_t *imgs[1] = {img};
     long count = -1;
     size_t n = size_t(h) * size_t(w);

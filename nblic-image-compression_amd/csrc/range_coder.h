@@ -47,9 +47,6 @@ constexpr uint32_t code13(uint32_t rec) { return (rec & 0xFFFu) | ((rec >> 3) & 
 constexpr size_t group_words(size_t bins, size_t lanes = 16) { return (bins + kGroupBins - 1) / kGroupBins * kGroupWords * lanes; }   // words of `bins` bins x `lanes` lanes
 void feed_pair_groups(RangeX8 &a, RangeX8 &b, const uint64_t *rows, const size_t *len);                    // 16 lanes
 void feed_triple_groups(RangeX8 &a, RangeX8 &b, RangeX8 &c, const uint64_t *rows, const size_t *len);      // 24 lanes: rows[(13 g + j) * 24 + lane]
-// one to three packs, each from a row stream of ITS OWN, eight lanes wide: rows_p[p][(13 g + j) * 8 + lane] -- the form k_mix
-// writes per pack of eight images (kernels_e1.hip); len[8 p + lane] = the lane's bins in this chunk
-void feed_packs(RangeX8 *const *packs, int n_packs, const uint64_t *const *rows_p, const size_t *len);
 void pack_groups_host(uint64_t *rows, int lane, const uint16_t *coded, size_t len, int lanes = 16);   // ORs one lane's records into zeroed rows (tests, the chunked self-check)
 
 bool have_avx512();

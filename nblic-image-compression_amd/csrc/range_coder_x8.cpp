@@ -315,17 +315,15 @@ void pack_groups_host(uint64_t *rows, int lane, const uint16_t *coded, size_t le
 
 // NP packs (8 * NP lanes, a word-row is NP aligned 64-byte loads) advanced in lock-step: two are a pack pair, three
 // ride a third pack along on whatever the core's ports have left (EPYC 9575F, one thread alone: 2150 -> 2380 Mbins/s).
-// Every pack has its own row stream: word j of pack p's group g is the 64-byte row at rows_p[p] + (13 g + j) * L (L = words
-// between consecutive rows of one pack: 8 for a stream that holds one pack -- what k_mix writes, pipeline.hip --, 8 NP
-// for NP packs interleaved in one stream with rows_p[p] = rows + 8 p).
 template <int NP>
-NB_TARGET NB_INLINE void feed_groups_np(RangeX8 *const *P, const uint64_t *const *rows_p, const size_t L, const size_t *len) {
+NB_TARGET NB_INLINE void feed_groups_np(RangeX8 *const *P, const uint64_t *rows, const size_t *len) {
+    constexpr size_t L = 8 * NP;
     Regs R[NP];
     Outs *O[NP];
     unsigned act[NP], full[NP];
     bool all_on = true, any = false;
     size_t m = SIZE_MAX, longest = 0;
-    alignas(64) uint64_t lv[8 * NP];
+    alignas(64) uint64_t lv[L];
     for (int p = 0; p < NP; p++) {
         R[p] = P[p]->st->L.r; O[p] = &P[p]->st->L.o;
         act[p] = 0; full[p] = (1u << P[p]->st->count) - 1u;
@@ -343,14 +341,14 @@ NB_TARGET NB_INLINE void feed_groups_np(RangeX8 *const *P, const uint64_t *const
     const size_t ahead = ahead_groups * kGroupWords * L;          // words; 2 groups = 3.3 KB per pack pair
     if (all_on && any) {
         for (; pos + kGroupBins <= m; pos += kGroupBins) {
-            const size_t grp = (pos >> 6) * (kGroupWords * L);            // word offset of the group in every pack's stream
+            const uint64_t *grp = rows + (pos >> 6) * (kGroupWords * L);
             for (int j = 0; j < int(kGroupWords); j++) {
-                const size_t row = grp + L * j;
+                const uint64_t *row = grp + L * j;
                 __m512i g[NP];
 #pragma GCC unroll 3
                 for (int p = 0; p < NP; p++) {
-                    _mm_prefetch((const char *)(rows_p[p] + row + ahead), _MM_HINT_T0);
-                    g[p] = _mm512_load_si512((const void *)(rows_p[p] + row));
+                    _mm_prefetch((const char *)(row + ahead + 8 * p), _MM_HINT_T0);
+                    g[p] = _mm512_load_si512((const void *)(row + 8 * p));
                 }
 #pragma GCC unroll 3
                 for (int p = 0; p < NP; p++) step_all<0x1000>(R[p], *O[p], g[p]);
@@ -363,32 +361,31 @@ NB_TARGET NB_INLINE void feed_groups_np(RangeX8 *const *P, const uint64_t *const
             }
             __m512i bins[NP];
 #pragma GCC unroll 3
-            for (int p = 0; p < NP; p++) bins[p] = _mm512_load_si512((const void *)(rows_p[p] + grp + L * 12));
+            for (int p = 0; p < NP; p++) bins[p] = _mm512_load_si512((const void *)(grp + L * 12 + 8 * p));
             __m512i bit = _mm512_set1_epi64(1ll << 52);
             for (int e = 0; e < 12; e++) {
-                const size_t row = grp + L * e;
+                const uint64_t *row = grp + L * e;
 #pragma GCC unroll 3
                 for (int p = 0; p < NP; p++)
-                    step_core(R[p], *O[p], _mm512_srli_epi64(_mm512_load_si512((const void *)(rows_p[p] + row)), 52), _mm512_testn_epi64_mask(bins[p], bit));
+                    step_core(R[p], *O[p], _mm512_srli_epi64(_mm512_load_si512((const void *)(row + 8 * p)), 52), _mm512_testn_epi64_mask(bins[p], bit));
                 bit = _mm512_slli_epi64(bit, 1);
             }
         }
     }
     // whatever is left (lanes of different length, a pack with idle lanes): one bin at a time, lanes masked by their length
     for (; pos < longest; pos++) {
-        const size_t grp0 = (pos >> 6) * (kGroupWords * L);
+        const uint64_t *grp = rows + (pos >> 6) * (kGroupWords * L);
         const size_t k = pos & 63;
         const __m512i at = _mm512_set1_epi64((long long)pos);
         for (int p = 0; p < NP; p++) {
             const __mmask8 kk = _mm512_cmplt_epu64_mask(at, _mm512_load_si512((const void *)(lv + 8 * p)));
             if (!kk) continue;
-            const uint64_t *grp = rows_p[p] + grp0;
             __m512i ev;
             if (k < 52) {
-                ev = _mm512_srl_epi64(_mm512_load_si512((const void *)(grp + L * (k >> 2))), _mm_cvtsi64_si128((long long)(13 * (k & 3))));
+                ev = _mm512_srl_epi64(_mm512_load_si512((const void *)(grp + L * (k >> 2) + 8 * p)), _mm_cvtsi64_si128((long long)(13 * (k & 3))));
             } else {
-                const __m512i bin = _mm512_srl_epi64(_mm512_load_si512((const void *)(grp + L * 12)), _mm_cvtsi64_si128((long long)(52 + (k - 52))));
-                ev = _mm512_or_si512(_mm512_srli_epi64(_mm512_load_si512((const void *)(grp + L * (k - 52))), 52),
+                const __m512i bin = _mm512_srl_epi64(_mm512_load_si512((const void *)(grp + L * 12 + 8 * p)), _mm_cvtsi64_si128((long long)(52 + (k - 52))));
+                ev = _mm512_or_si512(_mm512_srli_epi64(_mm512_load_si512((const void *)(grp + L * (k - 52) + 8 * p)), 52),
                                      _mm512_and_si512(_mm512_slli_epi64(bin, 12), _mm512_set1_epi64(0x1000)));
             }
             step<0x1000>(R[p], *O[p], ev, kk);
@@ -399,19 +396,11 @@ NB_TARGET NB_INLINE void feed_groups_np(RangeX8 *const *P, const uint64_t *const
 
 NB_TARGET void feed_pair_groups(RangeX8 &A, RangeX8 &B, const uint64_t *rows, const size_t *len) {
     RangeX8 *const P[2] = {&A, &B};
-    const uint64_t *const rp[2] = {rows, rows + 8};
-    feed_groups_np<2>(P, rp, 16, len);
+    feed_groups_np<2>(P, rows, len);
 }
 NB_TARGET void feed_triple_groups(RangeX8 &A, RangeX8 &B, RangeX8 &C, const uint64_t *rows, const size_t *len) {
     RangeX8 *const P[3] = {&A, &B, &C};
-    const uint64_t *const rp[3] = {rows, rows + 8, rows + 16};
-    feed_groups_np<3>(P, rp, 24, len);
-}
-// one, two or three packs, each from a row stream of its own (eight lanes wide): len[8 p + lane]
-NB_TARGET void feed_packs(RangeX8 *const *P, int n_packs, const uint64_t *const *rows_p, const size_t *len) {
-    if (n_packs == 1) feed_groups_np<1>(P, rows_p, 8, len);
-    else if (n_packs == 2) feed_groups_np<2>(P, rows_p, 8, len);
-    else feed_groups_np<3>(P, rows_p, 8, len);
+    feed_groups_np<3>(P, rows, len);
 }
 
 // leftovers of the byte accumulators, then the 4-byte flush of lo (NBLIC.c:576-586)
