@@ -119,6 +119,7 @@ __device__ __forceinline__ int prob_one(int c0, int c1) {
 struct LsqLds {
     double D[128];                           // statistics of the pixel about to be predicted: [s | b | A] (E + F)
     int8_t vn8[16];                          // regressors 0..9 (tap - 128); [14] = 0; [15] = x' - 128
+    int xch[3], bias_pub;                    // two-wave solve: the second wave's prediction / verdict / "redo with integers"; the regularisation strength for it
     i64 Mi[lsq::kMaxN][lsq::kMaxN + 1];      // integer redo of a pixel (rare): augmented system, terms
     i64 termi[lsq::kMaxN];
 };
@@ -218,37 +219,42 @@ __device__ __noinline__ int lsq_solve_int(LsqLds &S, int n, i64 bias, i64 *px_q1
 // a row has been placed its entries no longer change, so column k as seen at step k is what the back substitution
 // needs above the diagonal.
 // Returns the Q12 prediction of the lane's system in every lane of its group; ok = 0: a pivot was zero (NBLIC.c:118).
-template <int N>
+// WAVES = 2 (effort 3): the pixel's two systems are solved by the two WAVES of the image's workgroup, one system each
+// (model_body); a wave then has all four 16-lane rows for its system's columns.
+template <int N_, int WAVES_>
 struct SplitLayout {
-    static constexpr int R = N <= 8 ? 8 : 16, G = 64 / (2 * R), kS = (N + G) / G;       // kS = ceil((N + 1) / G)
+    static constexpr int N = N_, WAVES = WAVES_;
+    static constexpr int SYS = WAVES == 2 ? 1 : 2;                      // systems a wave solves side by side
+    static constexpr int R = (WAVES == 1 && N <= 8) ? 8 : 16;           // lanes per (system, column group)
+    static constexpr int G = 64 / (SYS * R);                            // column groups
+    static constexpr int kS = (N + G) / G;                              // column slots per lane: ceil((N + 1) / G)
 };
-template <int N, int CG>
+template <class L, int CG>
 __device__ __forceinline__ double bcast_group(double v) {
-    if constexpr (SplitLayout<N>::G == 2) return bcast_half<CG>(v);
+    if constexpr (L::G == 2) return bcast_half<CG>(v);
     else return bcast_row<CG>(v);
 }
-template <int N>
-__device__ __forceinline__ double group_max(double v) { if constexpr (SplitLayout<N>::R == 16) return row_max(v); else return half_row_max(v); }
-template <int N>
-__device__ __forceinline__ double group_sum(double v) { if constexpr (SplitLayout<N>::R == 16) return row_sum(v); else return half_row_sum(v); }
+template <class L>
+__device__ __forceinline__ double group_max(double v) { if constexpr (L::R == 16) return row_max(v); else return half_row_max(v); }
+template <class L>
+__device__ __forceinline__ double group_sum(double v) { if constexpr (L::R == 16) return row_sum(v); else return half_row_sum(v); }
 // column k of the system, from the group that owns it, in every group (k is a constant after unrolling)
-template <int N, int K>
-__device__ __forceinline__ double column_everywhere(const double (&M)[SplitLayout<N>::kS]) {
-    return bcast_group<N, K % SplitLayout<N>::G>(M[K / SplitLayout<N>::G]);
+template <class L, int K>
+__device__ __forceinline__ double column_everywhere(const double (&M)[L::kS]) {
+    return bcast_group<L, K % L::G>(M[K / L::G]);
 }
 
-template <int N, int K>
-__device__ __forceinline__ void eliminate_step(double (&M)[SplitLayout<N>::kS], double (&col)[N], int (&at)[N], int &at_sum, int &pos, double &diag, int &ok,
+template <class L, int K>
+__device__ __forceinline__ void eliminate_step(double (&M)[L::kS], double (&col)[L::N], int (&at)[L::N], int &at_sum, int &pos, double &diag, int &ok,
                                                const int live, const int row, const int cg, const int group_base4, lsq::Guard &g) {
-    using L = SplitLayout<N>;
     constexpr int k = K;
-    const double ck = column_everywhere<N, K>(M);
+    const double ck = column_everywhere<L, K>(M);
     col[k] = ck;
     // every lane prepares the reciprocal of ITS candidate while the pivot search runs: the winner's is fetched with
     // its value, and the reciprocal's dependent chain is off the step's critical path
     const double raw_c = lsq::recip_raw(ck);
     // pivot: largest |entry| of column k among the rows at positions >= k, first position wins (NBLIC.c:121-127)
-    const double key = group_max<N>((live & (pos >= k)) ? fma(fabs(ck), 256.0, double((15 - pos) * 16 + row)) : -1.0);
+    const double key = group_max<L>((live & (pos >= k)) ? fma(fabs(ck), 256.0, double((15 - pos) * 16 + row)) : -1.0);
     const int tag = int(fma(-256.0, floor(key * (1.0 / 256.0)), key));
     const int c = tag & 15, pc = 15 - (tag >> 4);
     const int src = group_base4 | (c << 2);
@@ -272,18 +278,19 @@ __device__ __forceinline__ void eliminate_step(double (&M)[SplitLayout<N>::kS], 
         g.see_entry(M[s]);
     }
 }
-template <int N, int K>
-__device__ __forceinline__ void eliminate_from(double (&M)[SplitLayout<N>::kS], double (&col)[N], int (&at)[N], int &at_sum, int &pos, double &diag, int &ok,
+template <class L, int K>
+__device__ __forceinline__ void eliminate_from(double (&M)[L::kS], double (&col)[L::N], int (&at)[L::N], int &at_sum, int &pos, double &diag, int &ok,
                                                const int live, const int row, const int cg, const int group_base4, lsq::Guard &g) {
-    if constexpr (K + 1 < N) {
-        eliminate_step<N, K>(M, col, at, at_sum, pos, diag, ok, live, row, cg, group_base4, g);
-        eliminate_from<N, K + 1>(M, col, at, at_sum, pos, diag, ok, live, row, cg, group_base4, g);
+    if constexpr (K + 1 < L::N) {
+        eliminate_step<L, K>(M, col, at, at_sum, pos, diag, ok, live, row, cg, group_base4, g);
+        eliminate_from<L, K + 1>(M, col, at, at_sum, pos, diag, ok, live, row, cg, group_base4, g);
     }
 }
 
-template <int N>
-__device__ __forceinline__ double lsq_solve_split(double (&M)[SplitLayout<N>::kS], const int row, const int cg, const int group_base4,
+template <class L>
+__device__ __forceinline__ double lsq_solve_split(double (&M)[L::kS], const int row, const int cg, const int group_base4,
                                                   const int8_t *vn8, lsq::Guard &g, int &ok) {
+    constexpr int N = L::N;
     // (flags are ints in vector registers: as booleans they would each pin a scalar register pair for the whole solve)
     const int live = row < N;
     int pos = row, at_sum = 0;
@@ -291,11 +298,11 @@ __device__ __forceinline__ double lsq_solve_split(double (&M)[SplitLayout<N>::kS
     double col[N];
     double diag = 1.0;
     ok = 1;
-    eliminate_from<N, 0>(M, col, at, at_sum, pos, diag, ok, live, row, cg, group_base4, g);
+    eliminate_from<L, 0>(M, col, at, at_sum, pos, diag, ok, live, row, cg, group_base4, g);
     at[N - 1] = N * (N - 1) / 2 - at_sum;
-    col[N - 1] = column_everywhere<N, N - 1>(M);
+    col[N - 1] = column_everywhere<L, N - 1>(M);
     diag = (live & (pos == N - 1)) ? col[N - 1] : diag;
-    double rhs = column_everywhere<N, N>(M);                             // every group finishes the solve alike
+    double rhs = column_everywhere<L, N>(M);                             // every group finishes the solve alike
     g.see_pivot(diag);                                                   // every divisor of the solve is some row's diagonal entry
     const double raw_own = lsq::recip_raw(diag);                         // every row's own reciprocal at once, fetched below
 #pragma unroll
@@ -310,7 +317,7 @@ __device__ __forceinline__ double lsq_solve_split(double (&M)[SplitLayout<N>::kS
     }
     const int v = vn8[live ? pos : 14];
     const double t = lsq::term(live ? rhs : 0.0, v, diag, lsq::recip_of_raw(raw_own), g);     // NBLIC.c:233-236
-    return double(kMid << lsq::kFb1) + group_sum<N>(live ? t : 0.0);
+    return double(kMid << lsq::kFb1) + group_sum<L>(live ? t : 0.0);
 }
 
 // Per-lane description of the one or two statistics entries a lane maintains ([s | b(n) | A(n x n)] order).
@@ -360,10 +367,13 @@ __device__ void lsq_row_prepare(const LsqEntries<N> &en, NB_GLOBAL double *F, NB
 }
 
 // The least-squares state of one image walk, shared by the encoder's model kernel and the decoder.
-template <int N>
+// WAVES = 1: one wave does everything, its two systems side by side (predict).  WAVES = 2: the image's workgroup has
+// two waves; wave 0 ("main") owns the statistics, the model and system 0, wave 1 solves system 1 and nothing else
+// (solve_one); the caller's barriers order the hand-overs through LsqLds (D, vn8, bias_pub in; xch out).
+template <int N, int WAVES = 1>
 struct LsqWalk {
     using T = LsqEntries<N>;
-    using L = SplitLayout<N>;
+    using L = SplitLayout<N, WAVES>;
     static constexpr int kS = L::kS;                                     // column slots per lane (lsq_solve_split)
     LsqEntries<N> en;
     double E[T::kSlots], Bj[T::kSlots], Fj[T::kSlots], Bn[T::kSlots], Fn[T::kSlots];
@@ -373,8 +383,10 @@ struct LsqWalk {
     int p1, p2;                                                          // Q12 predictions (<= 255 << 12)
     bool ok1, ok2;
 
-    __device__ void init(double *stats, int w_, int lane_, int bias_) {
-        lane = lane_; w = w_; row = lane & (L::R - 1); sys = (lane / L::R) & 1; cg = lane / (2 * L::R); group_base4 = (lane & ~(L::R - 1)) << 2;
+    __device__ void init(double *stats, int w_, int lane_, int wave_, int bias_) {
+        lane = lane_; w = w_; row = lane & (L::R - 1);
+        sys = L::SYS == 2 ? (lane / L::R) & 1 : wave_;
+        cg = lane / (L::SYS * L::R); group_base4 = (lane & ~(L::R - 1)) << 2;
         Bst = gp(stats); Fst = gp(stats) + size_t(w) * T::kStride;
         bias = bias_;
         en.init(lane);
@@ -393,20 +405,18 @@ struct LsqWalk {
             b[s] = Bst[at]; f[s] = Fst[at];
         }
     }
-    __device__ void row_begin(LsqLds &S) {
+    __device__ void row_begin(LsqLds &S) {                               // (the main wave only)
         lsq_row_prepare<N>(en, Fst, Bst, w, lane);
         __threadfence_block();
         wave_sync();
         load_cols(0, Bj, Fj);
 #pragma unroll
         for (int s = 0; s < T::kSlots; s++) { E[s] = 0.0; if (en.active[s]) S.D[lane + 64 * s] = Fj[s]; }
+        S.bias_pub = bias;
         wave_sync();
     }
-    // predictions of pixel j from S.D and S.vn8 (both complete and synchronised)
-    __device__ __forceinline__ void predict(LsqLds &S, int j) {
-        load_cols(j + 1, Bn, Fn);                                         // next pixel's columns: a whole pixel ahead of their use
-        lsq::bias_pair(bias, b1, b2);
-        const int bs = sys ? b2 : b1;
+    // the lane's slots of the system regularised with strength bs, from S.D; then the solve
+    __device__ __forceinline__ double solve_with(LsqLds &S, int bs, lsq::Guard &g, int &ok) const {
         const double reg = double(bs * N);
         double M[kS];
 #pragma unroll
@@ -419,11 +429,17 @@ struct LsqWalk {
             const double add = last_kind == 1 ? double(bs << lsq::kFb3) : (diag_slot == kS - 1 ? reg : 0.0);
             M[kS - 1] = last_kind == 2 ? 0.0 : v + add;
         }
+        const double p = lsq_solve_split<L>(M, row, cg, group_base4, S.vn8, g, ok);
+        return p < 0.0 ? 0.0 : (p > double(kMaxVal << lsq::kFb1) ? double(kMaxVal << lsq::kFb1) : p);
+    }
+    __device__ __forceinline__ int clamp_q12(i64 q) const { const i64 top = i64(kMaxVal) << lsq::kFb1; return int(q < 0 ? 0 : (q > top ? top : q)); }
+    // WAVES = 1: both predictions of pixel j from S.D and S.vn8 (complete and synchronised)
+    __device__ __forceinline__ void predict(LsqLds &S, int j) {
+        load_cols(j + 1, Bn, Fn);                                         // next pixel's columns: a whole pixel ahead of their use
+        lsq::bias_pair(bias, b1, b2);
         lsq::Guard g;
         int ok;
-        const double p = lsq_solve_split<N>(M, row, cg, group_base4, S.vn8, g, ok);
-        const double pc = p < 0.0 ? 0.0 : (p > double(kMaxVal << lsq::kFb1) ? double(kMaxVal << lsq::kFb1) : p);
-        const int pi = int(pc);
+        const int pi = int(solve_with(S, sys ? b2 : b1, g, ok));
         const u64 bad = __ballot(!g.ok());
         p1 = __builtin_amdgcn_readlane(pi, 0); p2 = __builtin_amdgcn_readlane(pi, L::R);      // system 0 / system 1 of column group 0
         const u64 okm = __ballot(ok != 0);
@@ -432,9 +448,31 @@ struct LsqWalk {
             i64 q1 = 0, q2 = 0;
             ok1 = lsq_solve_int(S, N, b1, &q1) != 0;
             ok2 = lsq_solve_int(S, N, b2, &q2) != 0;
-            const i64 top = i64(kMaxVal) << lsq::kFb1;
-            p1 = int(q1 < 0 ? 0 : (q1 > top ? top : q1)); p2 = int(q2 < 0 ? 0 : (q2 > top ? top : q2));
+            p1 = clamp_q12(q1); p2 = clamp_q12(q2);
         }
+    }
+    // WAVES = 2: this wave's ONE system.  The main wave keeps p1 / ok1 (and redoes its system with integers at once if
+    // it has to: the prediction itself depends on it); the other wave leaves prediction, verdict and "redo me" in S.xch
+    __device__ __forceinline__ void solve_one(LsqLds &S, int j, bool main) {
+        if (main) load_cols(j + 1, Bn, Fn);
+        lsq::bias_pair(main ? bias : S.bias_pub, b1, b2);
+        lsq::Guard g;
+        int ok;
+        const int pi = int(solve_with(S, main ? b1 : b2, g, ok));
+        const bool bad = __ballot(!g.ok()) != 0;
+        const int mine = __builtin_amdgcn_readlane(pi, 0);
+        const bool ok_mine = (__ballot(ok != 0) & 1ull) != 0;
+        if (main) {
+            p1 = mine; ok1 = ok_mine;
+            if (bad) { i64 q1 = 0; ok1 = lsq_solve_int(S, N, b1, &q1) != 0; p1 = clamp_q12(q1); }
+        } else {
+            S.xch[0] = mine; S.xch[1] = int(ok_mine); S.xch[2] = int(bad);
+        }
+    }
+    // WAVES = 2, main wave, after the barrier that follows solve_one: the other system's result
+    __device__ __forceinline__ void take_other(LsqLds &S) {
+        p2 = S.xch[0]; ok2 = S.xch[1] != 0;
+        if (S.xch[2]) { i64 q2 = 0; ok2 = lsq_solve_int(S, N, b2, &q2) != 0; p2 = clamp_q12(q2); }
     }
     // fold the coded pixel in (NBLIC.c:242-283, :882-893) and publish the next pixel's statistics; S.vn8[15] = x' - 128 is set
     __device__ __forceinline__ void update(LsqLds &S, int j, int xr, int p1_used) {
@@ -454,6 +492,7 @@ struct LsqWalk {
             E[s] = en.decay(E[s], s) + b;
         }
         if (ok1 && ok2) bias = (iabs(p1 - xq) > iabs(p2 - xq)) ? b2 : b1;
+        if (WAVES == 2) S.bias_pub = bias;
 #pragma unroll
         for (int s = 0; s < T::kSlots; s++) {
             if (en.active[s]) S.D[lane + 64 * s] = E[s] + Fn[s];
@@ -522,17 +561,27 @@ struct TapWindow {
 // from the reconstruction in memory.  The two variants are separate code: one generic accessor would
 // turn every tap into a flat load with a branch and a full wait of its own.
 // A launch works on rows [i0, i1) of the image (serial_engine.h: resumable launches).
-template <int N, bool CACHED>
+// WAVES = 2 (effort 3): the image's workgroup has a second wave whose only job is the pixel's SECOND system -- two
+// 10 x 10 eliminations are two thirds of a pixel, they are independent, and the second one's result is not needed
+// before the regularisation strength of the NEXT pixel is chosen.  With a wave to itself a system has four column
+// groups instead of two (19 + 9 multiply-divides per pixel on the main wave's path instead of 34 + 9).  Per pixel two
+// workgroup barriers: one when the statistics and regressors of the pixel stand in LDS (the second wave is waiting
+// there), one before the main wave picks up the second wave's prediction (it has long been left there: the main wave
+// still had the whole context model to do).
+__device__ __forceinline__ void block_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int N, bool CACHED, int WAVES>
 __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const SerialJob &J, const int rs, const int i0, const int i1, int &bias_io) {
-    const int w = J.w, lane = int(threadIdx.x);
+    const int w = J.w, lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+    const bool main = wave == 0;
     const NearParams np = near_params(J.near);
     const auto img = gp(J.img);
     const auto recon = gp(J.recon);
     const auto rec1 = gp(J.rec1);
     const auto pxs = gp(J.pxs);
-    LsqWalk<N> lw;
-    if constexpr (N > 0) lw.init(J.stats, w, lane, bias_io);
-    if (CACHED && i0 > 0) {                                              // resuming: the two rows above come back from the reconstruction
+    LsqWalk<N, WAVES> lw;
+    if constexpr (N > 0) lw.init(J.stats, w, lane, wave, bias_io);
+    if (main && CACHED && i0 > 0) {                                      // resuming: the two rows above come back from the reconstruction
         const auto prev = J.recon ? gp(const_cast<const uint8_t *>(J.recon)) : img;      // lossless: the reconstruction IS the input
         for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
             uint8_t *dst = rows + (r % 3) * rs;
@@ -544,7 +593,7 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
     for (int i = i0; i < i1; i++) {
         uint8_t *r0 = rows + (i % 3) * rs, *r1 = rows + ((i + 2) % 3) * rs, *r2 = rows + ((i + 1) % 3) * rs;
         const size_t row_at = size_t(i) * size_t(w), out_at = size_t(i - J.out_row0) * size_t(w);
-        if (CACHED) {                                                    // the row's ORIGINAL pixels; each is replaced by its reconstruction once coded
+        if (main && CACHED) {                                            // the row's ORIGINAL pixels; each is replaced by its reconstruction once coded
             for (int c = lane; c < w; c += 64) r0[c] = img[row_at + c];
             wave_sync();
         }
@@ -552,49 +601,61 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
             if (CACHED) return int((r == i ? r0 : (r == i - 1 ? r1 : r2))[c]);
             return int(recon[size_t(r) * size_t(w) + size_t(c)]);
         };
-        if constexpr (N > 0) lw.row_begin(S.q);
+        if constexpr (N > 0) { if (main) lw.row_begin(S.q); }
         int err = 0;
         TapWindow tw;
         int x_next = 0;
-        if (CACHED) { tw.row_start(r0, r1, r2, w); x_next = r0[0]; }
+        if (main && CACHED) { tw.row_start(r0, r1, r2, w); x_next = r0[0]; }
         for (int j = 0; j < w; j++) {
-            const Taps t = CACHED ? tw.taps(w, i, j) : sample_taps(pix, w, i, j);
-            const int x = CACHED ? x_next : int(img[row_at + j]);
-            if (CACHED) x_next = r0[j + 1 < w ? j + 1 : j];                // the next original pixel: requested a pixel ahead
-            int px0, p1_used = 0;
-            if constexpr (N > 0) {
-                store_regressors(S.q.vn8, t);
-                wave_sync();
-                lw.predict(S.q, j);
-                if (lw.ok1) { px0 = (lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1; p1_used = lw.p1; }
-                else { px0 = predict(t); p1_used = px0 << lsq::kFb1; }
-            } else {
-                px0 = predict(t);
+            Taps t{};
+            int x = 0;
+            if (main) {
+                t = CACHED ? tw.taps(w, i, j) : sample_taps(pix, w, i, j);
+                x = CACHED ? x_next : int(img[row_at + j]);
+                if (CACHED) x_next = r0[j + 1 < w ? j + 1 : j];            // the next original pixel: requested a pixel ahead
+                if constexpr (N > 0) store_regressors(S.q.vn8, t);
             }
-            const int delta = activity(t, err);
-            const Level L = level_from(S.qlut[delta < 200 ? delta : 200]);
-            const int adr = context_address(t, L.qu, px0);
-            const int v = S.ctx[adr];
-            const int sign = bias_sign(v), px = bias_apply(v, px0);
-            const int y = residual_to_symbol(x, px, sign, np);
-            const int xr = symbol_to_pixel(y, px, sign, np);
-            err = clip_err(xr, px0);
-            S.ctx[adr] = bias_update(v, err);
-            if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else { recon[row_at + j] = uint8_t(xr); __threadfence_block(); }
-            S.rec_ring[j & 63] = pack_s1(px0, adr, L);
-            S.pxs_ring[j & 63] = uint16_t(px | (sign << 8));
-            if ((j & 63) == 63 || j == w - 1) {                          // a lane per record: coalesced stores
-                const int base = j & ~63;
-                if (base + lane <= j) { rec1[out_at + base + lane] = S.rec_ring[lane]; pxs[out_at + base + lane] = S.pxs_ring[lane]; }
+            int px0 = 0, p1_used = 0;
+            if constexpr (N > 0) {
+                if constexpr (WAVES == 2) { block_sync(); lw.solve_one(S.q, j, main); }
+                else { wave_sync(); lw.predict(S.q, j); }
+            }
+            int xr = 0;
+            if (main) {
+                if constexpr (N > 0) {
+                    if (lw.ok1) { px0 = (lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1; p1_used = lw.p1; }
+                    else { px0 = predict(t); p1_used = px0 << lsq::kFb1; }
+                } else {
+                    px0 = predict(t);
+                }
+                const int delta = activity(t, err);
+                const Level L = level_from(S.qlut[delta < 200 ? delta : 200]);
+                const int adr = context_address(t, L.qu, px0);
+                const int v = S.ctx[adr];
+                const int sign = bias_sign(v), px = bias_apply(v, px0);
+                const int y = residual_to_symbol(x, px, sign, np);
+                xr = symbol_to_pixel(y, px, sign, np);
+                err = clip_err(xr, px0);
+                S.ctx[adr] = bias_update(v, err);
+                if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else { recon[row_at + j] = uint8_t(xr); __threadfence_block(); }
+                S.rec_ring[j & 63] = pack_s1(px0, adr, L);
+                S.pxs_ring[j & 63] = uint16_t(px | (sign << 8));
+                if ((j & 63) == 63 || j == w - 1) {                      // a lane per record: coalesced stores
+                    const int base = j & ~63;
+                    if (base + lane <= j) { rec1[out_at + base + lane] = S.rec_ring[lane]; pxs[out_at + base + lane] = S.pxs_ring[lane]; }
+                }
+                if constexpr (N > 0) S.q.vn8[15] = int8_t(xr - kMid);
             }
             if constexpr (N > 0) {
-                S.q.vn8[15] = int8_t(xr - kMid);
-                wave_sync();
-                lw.update(S.q, j, xr, p1_used);
-                wave_sync();
+                if constexpr (WAVES == 2) block_sync(); else wave_sync();
+                if (main) {
+                    if constexpr (WAVES == 2) lw.take_other(S.q);
+                    lw.update(S.q, j, xr, p1_used);
+                    wave_sync();
+                }
             }
         }
-        if (CACHED && J.recon) {
+        if (main && CACHED && J.recon) {
             wave_sync();
             for (int c = lane; c < w; c += 64) recon[row_at + c] = r0[c];
         }
@@ -602,27 +663,28 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
     if constexpr (N > 0) bias_io = lw.bias;
 }
 
-template <int N>
-__global__ void __launch_bounds__(64) k_serial_model(const SerialJob *__restrict__ jobs, int dyn_bytes) {
+template <int N, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_serial_model(const SerialJob *__restrict__ jobs, int dyn_bytes) {
     __shared__ ModelLds S;
     extern __shared__ __align__(16) uint8_t rows[];
     const SerialJob &J = jobs[blockIdx.x];
     const auto st = gp(J.state);
     const auto st_ctx = gp(reinterpret_cast<int *>(J.state + 1));
-    const int lane = int(threadIdx.x);
-    if (st->status != kRunning) return;                                  // finished in an earlier launch
+    const int tid = int(threadIdx.x);
+    if (st->status != kRunning) return;                                  // finished in an earlier launch (every wave of the workgroup sees the same)
     const int i0 = st->next_row, i1 = i0 + J.rows < J.h ? i0 + J.rows : J.h;
     int bias = i0 ? st->bias : lsq::kBiasInit;
-    for (int k = lane; k < kContexts; k += 64) S.ctx[k] = i0 ? st_ctx[k] : 0;
-    fill_qlut(S.qlut);
-    if (lane < 16) S.q.vn8[lane] = 0;
-    wave_sync();
+    if (WAVES == 2) block_sync();                                        // every wave has read the record before wave 0 may write it again (a one-row image)
+    for (int k = tid; k < kContexts; k += 64 * WAVES) S.ctx[k] = i0 ? st_ctx[k] : 0;
+    if (tid < 64) fill_qlut(S.qlut);
+    if (tid < 16) S.q.vn8[tid] = 0;
+    if (WAVES == 2) block_sync(); else wave_sync();
     const int rs = (J.w + 15) & ~15;
-    if (3 * rs <= dyn_bytes) model_body<N, true>(S, rows, J, rs, i0, i1, bias);
-    else model_body<N, false>(S, rows, J, rs, i0, i1, bias);
-    wave_sync();
-    if (i1 < J.h) for (int k = lane; k < kContexts; k += 64) st_ctx[k] = S.ctx[k];
-    if (lane == 0) { st->next_row = i1; st->bias = bias; st->status = i1 < J.h ? kRunning : kDone; }
+    if (3 * rs <= dyn_bytes) model_body<N, true, WAVES>(S, rows, J, rs, i0, i1, bias);
+    else model_body<N, false, WAVES>(S, rows, J, rs, i0, i1, bias);
+    if (WAVES == 2) block_sync(); else wave_sync();
+    if (i1 < J.h) for (int k = tid; k < kContexts; k += 64 * WAVES) st_ctx[k] = S.ctx[k];
+    if (tid == 0) { st->next_row = i1; st->bias = bias; st->status = i1 < J.h ? kRunning : kDone; }
 }
 
 // ---- decoder: the whole NBLIC loop (NBLIC.c:749-908 with decode = 1) ----------------------------
@@ -668,7 +730,7 @@ __device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const Se
     const uint64_t ktab = level_shift_table(k_step);
     const auto out = gp(J.recon);
     LsqWalk<N> lw;
-    if constexpr (N > 0) lw.init(J.stats, w, lane, bias_io);
+    if constexpr (N > 0) lw.init(J.stats, w, lane, 0, bias_io);
     uint32_t lo = cs[0], hi = cs[1], window = cs[2];
     if (CACHED && i0 > 0) {                                              // resuming: the two rows above come back from the decoded plane
         for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
@@ -1033,28 +1095,35 @@ int serial_selftest(hipStream_t s) {
 
 // ---- launchers ----------------------------------------------------------------------------------
 constexpr int kLdsBudget = 160 * 1024;
+constexpr int kTwoWaveImages = 64;               // effort-3 launches of at most this many images give every image a second wave
 constexpr int lds_room(size_t static_lds) { return int(kLdsBudget - static_lds - 256) & ~15; }
 
 bool serial_model_rows_fit(int w) { return 3 * ((w + 15) & ~15) <= lds_room(sizeof(ModelLds)); }
 
 template <class K>
-static bool launch_rows(K kernel, size_t static_lds, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
+static bool launch_rows(K kernel, size_t static_lds, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s, int threads = 64) {
     int max_w = 1;
     for (int k = 0; k < n; k++) max_w = h_jobs[k].w > max_w ? h_jobs[k].w : max_w;
     const int room = lds_room(static_lds);
     int dyn = 3 * ((max_w + 15) & ~15);
     if (dyn > room) dyn = room;                  // wider images fall back to taps from memory (the kernel compares per job)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) return false;
-    hipLaunchKernelGGL(kernel, dim3(unsigned(n)), dim3(64), size_t(dyn), s, d_jobs, dyn);
+    hipLaunchKernelGGL(kernel, dim3(unsigned(n)), dim3(unsigned(threads)), size_t(dyn), s, d_jobs, dyn);
     return hipGetLastError() == hipSuccess;
 }
 
 bool serial_model_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
     if (n <= 0) return true;
     switch (h_jobs[0].effort) {
-        case 1: return launch_rows(k_serial_model<0>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
-        case 2: return launch_rows(k_serial_model<6>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
-        default: return launch_rows(k_serial_model<10>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
+        case 1: return launch_rows(k_serial_model<0, 1>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
+        case 2: return launch_rows(k_serial_model<6, 1>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
+        default:
+            // Effort 3, few images: two waves per image, a system each -- 4.39 instead of 4.5 us per pixel per image (the
+            // two barriers per pixel eat two thirds of what the shorter elimination saves).  Many images: the second wave
+            // would take a SIMD slot from another image for a 3 % shorter chain (2048 images: 156 against 261 Mpx/s), so
+            // a batch that can fill the GPU with single waves keeps them.
+            if (n <= kTwoWaveImages) return launch_rows(k_serial_model<10, 2>, sizeof(ModelLds), d_jobs, h_jobs, n, s, 128);
+            return launch_rows(k_serial_model<10, 1>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
     }
 }
 
