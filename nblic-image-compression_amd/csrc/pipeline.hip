@@ -28,6 +28,7 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -1348,8 +1349,16 @@ static bool decode_batch(nblic_amd_ctx *c, int n, const unsigned char *const *st
 // the copy comes back short instead of raising a signal, and a stream that sits right at the end of a mapping is read
 // exactly to its last byte.
 static size_t safe_copy(nblic_amd_ctx *c, void *dst, const void *src, size_t n) {
-    if (c->feed_pipe[0] < 0 && pipe(c->feed_pipe) != 0) { c->feed_pipe[0] = c->feed_pipe[1] = -1; return 0; }
+    if (c->feed_pipe[0] < 0) {
+        if (pipe(c->feed_pipe) != 0) { c->feed_pipe[0] = c->feed_pipe[1] = -1; return 0; }
+        // never block: nobody else reads this pipe, so a write that does not fit would wait for ever (a process over its
+        // pipe quota gets single-page pipes)
+        fcntl(c->feed_pipe[1], F_SETFL, fcntl(c->feed_pipe[1], F_GETFL) | O_NONBLOCK);
+        fcntl(c->feed_pipe[0], F_SETFD, FD_CLOEXEC); fcntl(c->feed_pipe[1], F_SETFD, FD_CLOEXEC);
+    }
     const size_t page = size_t(sysconf(_SC_PAGESIZE));
+    const long pipe_cap = fcntl(c->feed_pipe[1], F_GETPIPE_SZ);
+    const size_t burst = pipe_cap >= long(page) ? (size_t(pipe_cap) < size_t(65536) ? size_t(pipe_cap) & ~(page - 1) : size_t(65536)) : page;
     size_t done = 0;
     while (done < n) {
         // The pipe takes a write in page-sized pieces and DROPS a piece it could only copy in part, so the pieces have to
@@ -1358,7 +1367,7 @@ static size_t safe_copy(nblic_amd_ctx *c, void *dst, const void *src, size_t n) 
         // readable memory ends.
         const size_t addr = size_t(reinterpret_cast<uintptr_t>(src)) + done;
         const size_t to_boundary = page - (addr & (page - 1));
-        size_t want = (addr & (page - 1)) ? to_boundary : size_t(65536);
+        size_t want = (addr & (page - 1)) ? to_boundary : burst;               // what the pipe holds: a short return then means "memory ends", never "pipe full"
         if (want > n - done) want = n - done;
         const ssize_t k = write(c->feed_pipe[1], static_cast<const char *>(src) + done, want);
         if (k <= 0) break;                                                          // EFAULT: not one more byte can be read
