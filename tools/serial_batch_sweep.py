@@ -39,4 +39,12 @@ for mode in args.modes.split(","):
             t0 = time.perf_counter(); d = ctx.decode_batch(s); dd = time.perf_counter() - t0
             line["decode_Mpx_s"] = round(n * H * W / dd / 1e6, 1); line["decode_ok"] = all(x is not None for x in d)
         print(json.dumps(line), flush=True)
+if args.decode:                                          # effort 0 (QNBLIC): batch decode, the same sweep
+    for n in batches:
+        imgs = [base[k % len(base)] for k in range(n)]
+        q = ctx.qencode_batch(imgs)
+        ctx.decode_batch(q[: min(n, 64)])
+        t0 = time.perf_counter(); d = ctx.decode_batch(q); dd = time.perf_counter() - t0
+        print(json.dumps({"mode": "-e0 decode (QNBLIC)", "size": f"{H}x{W}", "images": n, "decode_Mpx_s": round(n * H * W / dd / 1e6, 1),
+                          "decode_ok": all(x is not None and (x[0] == im).all() for x, im in zip(d, imgs))}), flush=True)
 ctx.close()
