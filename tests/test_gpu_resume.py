@@ -184,3 +184,21 @@ def test_band_stream_equals_one_piece_and_survives_checkpoints(gpu_ctx, pkg, ora
         assert b"".join(pieces) == want, (img.shape, near, effort)
         assert prog["sha256"] == hashlib.sha256(want).hexdigest() and prog["bytes_total"] == len(want)
         assert np.array_equal(rec, wrec)
+
+
+def test_two_wave_effort3_launches_are_exact_and_repeatable(gpu_ctx, pkg, oracle):
+    """Effort-3 launches of at most 64 images give every image a second wave for the pixel's second system
+    (serial_engine.hip model_body<..., WAVES = 2>: barriers order the hand-overs through LDS).  64 images side by side,
+    three times over: every stream the oracle's, every time; then 65 images (one wave each) give the same streams."""
+    imgs = [inputs.syn1(40 + (k % 5) * 7, 48 + (k % 7) * 9, k + 1) if k % 3 else inputs.make("noise", 33 + k % 11, 57) for k in range(65)]
+    nears = [(0, 1, 3)[k % 3] for k in range(65)]
+    want = [oracle.encode(im, n, 3)[0] for im, n in zip(imgs, nears)]
+    ctx = pkg.Context(device=0, n_slots=65, n_coders=4, n_groups=1, n_host_buffers=80)
+    try:
+        for rep in range(3):
+            got, _ = ctx.encode_modes(imgs[:64], nears[:64], [3] * 64)
+            assert got == want[:64], rep
+        got, _ = ctx.encode_modes(imgs, nears, [3] * 65)
+        assert got == want
+    finally:
+        ctx.close()
