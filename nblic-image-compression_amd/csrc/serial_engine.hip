@@ -904,6 +904,70 @@ struct QDecodeLds {
     uint32_t sbuf[256];
 };
 
+// ---- the pixel's model spread over the lanes (rows >= 2 of an image whose rows fit in LDS) ---------
+// Every cost of the seven-direction predictor, every term of the activity and every comparison of the context address
+// has the shape  2 X - Y - Z  over the taps (|a - e| is |2a - e - e| / 2; tap f is 2f - f - 0), so a lane takes ONE term:
+// its three operands come from the rows above in LDS at the lane's own offsets (read a pixel ahead), the two taps of the
+// row being decoded (a, e) are added in from registers, and what took ~250 scalar instructions per pixel is
+//   lanes  0..27  the 7 x 4 cost terms (direction d in quad d): one absolute difference, two quad adds, a minimum
+//                 over keys (cost << 3 | direction: the first minimum wins, QNBLIC.c:128-143) and a sum over the rows;
+//   lanes 28..33  the six terms of the activity (QNBLIC.c:152-161), twice their value, in quads 7 and 8;
+//   lanes 36..43  the eight comparison values of the context address (QNBLIC.c:164-173), bit 0 first, compared with
+//                 the prediction in one instruction whose lane mask IS the address byte;
+// the thresholds of the level (11) and of the blend weight (7) are compared lane-wise too and counted with s_bcnt1.
+enum QTap : int8_t { qZ, qA, qE, qB, qC, qD, qQ, qF, qG, qH, qR, qS };
+struct QLaneConst {
+    int8_t sel[3], dx[3];                    // X, Y, Z: 0 the zero byte / 1 row i-1 / 2 row i-2, and the column offset
+    int8_t a2, ce, sh;                       // + a2 * a into 2X; + ce * e into Y + Z; the prediction is shifted left by sh for the comparison
+    int8_t ca, cb, cc, cd;                   // lanes 0..6: the direction's extrapolation  ca a + cb b + cc c + cd d  (twice the neighbour)
+    int16_t thr_level, thr_weight;           // lanes 0..10 / 0..6 (0x7FFF elsewhere)
+    int32_t key_or, sum_and;                 // lanes 0..27: direction / all ones; elsewhere 0x7FFFFFFF / 0
+};
+struct QLaneTable { QLaneConst l[64]; };
+constexpr int kQRowPad = 8;                  // a row's margins in LDS: 2 columns left, >= 4 right (+ rounding to 16)
+constexpr QLaneTable make_qlanes() {
+    constexpr QTap terms[44][3] = {
+        {qA, qE, qE}, {qC, qQ, qQ}, {qB, qC, qC}, {qD, qB, qB},          // west        2 (|a-e| + |c-q| + |b-c| + |d-b|)
+        {qA, qC, qC}, {qC, qH, qH}, {qB, qF, qF}, {qD, qG, qG},          // north
+        {qA, qQ, qQ}, {qC, qS, qS}, {qB, qH, qH}, {qD, qF, qF},          // north-west
+        {qA, qB, qB}, {qC, qF, qF}, {qB, qG, qG}, {qD, qR, qR},          // north-east
+        {qA, qE, qQ}, {qC, qQ, qS}, {qB, qC, qH}, {qD, qB, qF},          // between west and north-west
+        {qA, qQ, qC}, {qC, qS, qH}, {qB, qH, qF}, {qD, qF, qG},          // between north-west and north
+        {qA, qC, qB}, {qC, qH, qF}, {qB, qF, qG}, {qD, qG, qR},          // between north and north-east
+        {qA, qE, qE}, {qB, qC, qC}, {qB, qD, qD}, {qA, qC, qC},          // activity
+        {qB, qF, qF}, {qD, qG, qG}, {qZ, qZ, qZ}, {qZ, qZ, qZ},
+        {qB, qF, qZ}, {qA, qE, qZ}, {qF, qF, qZ}, {qZ, qZ, qZ},          // 2b - f, 2a - e, f, e (2e against twice the prediction)
+        {qD, qD, qZ}, {qC, qC, qZ}, {qB, qB, qZ}, {qA, qZ, qZ}};         // d, c, b, a (2a against twice the prediction)
+    constexpr int8_t row_of[12] = {0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2};   // Z A E B C D Q F G H R S
+    constexpr int8_t col_of[12] = {0, 0, 0, 0, -1, 1, -2, 0, 1, -1, 2, -2};
+    constexpr int8_t ang[7][4] = {{2, 0, 0, 0}, {0, 2, 0, 0}, {0, 0, 2, 0}, {0, 0, 0, 2}, {1, 0, 1, 0}, {0, 1, 1, 0}, {0, 1, 0, 1}};
+    constexpr int16_t levels[11] = {1, 2, 4, 6, 9, 15, 25, 39, 63, 101, 151};
+    constexpr int16_t weights[7] = {5, 12, 34, 78, 194, 431, 601};
+    QLaneTable t{};
+    for (int k = 0; k < 64; k++) {
+        QLaneConst &c = t.l[k];
+        for (int o = 0; o < 3; o++) {
+            const QTap tap = k < 44 ? terms[k][o] : qZ;
+            c.sel[o] = row_of[tap]; c.dx[o] = col_of[tap];
+            if (o == 0 && tap == qA) c.a2 = 2;
+            if (o > 0 && tap == qE) c.ce += 1;
+        }
+        if (k == 39) { c.ce = -2; c.sh = 1; }
+        if (k == 43) c.sh = 1;
+        if (k < 7) { c.ca = ang[k][0]; c.cb = ang[k][1]; c.cc = ang[k][2]; c.cd = ang[k][3]; }
+        c.thr_level = k < 11 ? levels[k] : int16_t(0x7FFF);
+        c.thr_weight = k < 7 ? weights[k] : int16_t(0x7FFF);
+        c.key_or = k < 28 ? k >> 2 : 0x7FFFFFFF;
+        c.sum_and = k < 28 ? -1 : 0;
+    }
+    return t;
+}
+__device__ const QLaneTable kQLanes = make_qlanes();
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int min_u(int a, int b) { return int(unsigned(a) < unsigned(b) ? unsigned(a) : unsigned(b)); }
+
 // What a pixel costs here is the chain  rANS state -> symbol -> pixel -> error -> (next pixel's level) -> ...  with a
 // dependent LDS round trip (~64 cycles) at every table lookup, and the ~200 instructions of the predictor next to it.
 // So: the level (cheap, needs only the taps and the last error) is computed FIRST and the symbol search started from it
@@ -935,6 +999,7 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
                                             StreamWindow &sw, QRans &rans, const bool final_, const size_t row_need, int &stop) {
     const int lane = int(threadIdx.x), w = J.w;
     const auto out = gp(J.recon);
+    const QLaneConst lc = kQLanes.l[lane];
     if (CACHED && i0 > 0) {
         for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
             uint8_t *dst = rows + (r % 3) * rs;
@@ -964,16 +1029,60 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
             return px_out;
         };
         if (CACHED && i >= 2) {
-            TapWindow tw;
-            tw.row_start(r0, r1, r2, w);
-            const int u0 = r1[0];
+            // the rows above, with their edge pixels repeated two columns out (QNBLIC.c:48-79 clamps the columns)
+            if (lane < 8) {
+                uint8_t *r = lane < 4 ? r1 : r2;
+                const int k = lane & 3;
+                r[k < 2 ? -1 - k : w + k - 2] = r[k < 2 ? 0 : w - 1];
+            }
+            wave_sync();
+            const int base1 = int(r1 - rows), base2 = int(r2 - rows);
+            int adX = lc.sel[0] == 0 ? -4 : (lc.sel[0] == 1 ? base1 : base2) + lc.dx[0];
+            int adY = lc.sel[1] == 0 ? -4 : (lc.sel[1] == 1 ? base1 : base2) + lc.dx[1];
+            int adZ = lc.sel[2] == 0 ? -4 : (lc.sel[2] == 1 ? base1 : base2) + lc.dx[2];
+            const int stX = lc.sel[0] != 0, stY = lc.sel[1] != 0, stZ = lc.sel[2] != 0;
+            int a = r1[0], e = a;                                         // the window hands on row i-1's first pixel
+            int X = rows[adX], Y = rows[adY], Z = rows[adZ];
             for (int j = 0; j < w; j++) {
-                Taps n;
-                n.a = j >= 1 ? tw.A : u0; n.e = j >= 2 ? tw.E : u0;
-                n.b = tw.B; n.c = tw.C; n.d = tw.D; n.q = tw.Q; n.f = tw.F; n.g = tw.G; n.h = tw.H; n.r = tw.R; n.s = tw.S; n.t = 0;
-                const int px_out = pixel(n, j);
+                adX += stX; adY += stY; adZ += stZ;
+                const int Xn = rows[adX], Yn = rows[adY], Zn = rows[adZ];            // the next pixel's operands
+                // everything that does not wait for the pixel on the left
+                const int s_yz = __mul24(e, int(lc.ce)) + (Y + Z);
+                const int x2 = X << 1;
+                const int b = __builtin_amdgcn_readlane(X, 2), c = __builtin_amdgcn_readlane(X, 1), d = __builtin_amdgcn_readlane(X, 3);
+                const int f = __builtin_amdgcn_readlane(Y, 6);
+                const int ang_bcd = __mul24(b, int(lc.cb)) + __mul24(c, int(lc.cc)) + __mul24(d, int(lc.cd));
+                // the lane's term
+                const int X2 = x2 + __mul24(a, int(lc.a2));
+                const int V = X2 - s_yz;
+                int Q = V < 0 ? -V : V;
+                Q += dpp_i32<kQuadX1>(Q); Q += dpp_i32<kQuadX2>(Q);                   // the quad's four terms
+                // level: the symbol search starts from it
+                const int act = ((__builtin_amdgcn_readlane(Q, 28) + __builtin_amdgcn_readlane(Q, 32)) >> 1) + 2 * iabs(err);
+                const int qd = __builtin_popcountll(__ballot(int(lc.thr_level) <= act));
+                const int y = rans.symbol(S, qd, sw);
+                // prediction
+                int key = (Q << 3) | lc.key_or, sum = Q & lc.sum_and;
+                key = min_u(key, dpp_i32<kRor4>(key)); key = min_u(key, dpp_i32<kRor8>(key));
+                sum += dpp_i32<kRor4>(sum); sum += dpp_i32<kRor8>(sum);
+                const int k_min = min_u(__builtin_amdgcn_readlane(key, 0), __builtin_amdgcn_readlane(key, 16));
+                const int total = __builtin_amdgcn_readlane(sum, 0) + __builtin_amdgcn_readlane(sum, 16);
+                const int best = k_min >> 3, dir = k_min & 7;
+                const int spread = (total - 7 * best) >> 3;
+                const int wt = __builtin_popcountll(__ballot(int(lc.thr_weight) <= spread));
+                const int ang = __builtin_amdgcn_readlane(ang_bcd + __mul24(a, int(lc.ca)), dir);
+                const int lin = iclip(9 * (a + b) + 2 * (d - c) - e - f, 0, 16 * kMaxVal);
+                const int px0 = (8 * wt * ang + (8 - wt) * lin + 64) >> 7;
+                const int adr = (qd << 8) | int((__ballot((px0 << int(lc.sh)) > V) >> 36) & 0xFFull);
+                const int v = S.ctx[adr];
+                const int sign = (v >> 10) & 1;
+                const int px = iclip(px0 + (v >> 11) + sign, 0, kMaxVal);
+                const int px_out = __builtin_amdgcn_readfirstlane(symbol_to_pixel(y, px, sign, 0));
+                err = px_out - px0;
+                S.ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
                 r0[j] = uint8_t(px_out);
-                tw.advance(r1, r2, w, j, px_out);
+                e = a; a = px_out;
+                X = Xn; Y = Yn; Z = Zn;
                 if (sw.dry) break;
             }
         } else {
@@ -998,7 +1107,7 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
 
 __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restrict__ jobs, int dyn_bytes) {
     __shared__ QDecodeLds S;
-    extern __shared__ __align__(16) uint8_t rows[];
+    extern __shared__ __align__(16) uint8_t rows_raw[];
     const SerialJob &J = jobs[blockIdx.x];
     const auto st = gp(J.state);
     const auto st_ctx = gp(reinterpret_cast<int *>(J.state + 1));
@@ -1016,7 +1125,11 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restri
     }
     if (lane < 2) S.span[3072 + lane] = 0;
     wave_sync();
-    const int rs = (w + 15) & ~15;
+    // a row in LDS: two columns of margin on the left (after the four bytes in front of row 0, which hold zero for the
+    // lanes without an operand) and at least four on the right -- the lane-parallel model reads the clamped columns there
+    const int rs = (w + kQRowPad + 15) & ~15;
+    uint8_t *rows = rows_raw + 4;
+    if (lane < 4) rows_raw[lane] = 0;
     StreamWindow sw;
     sw.start(J.stream, avail, size_t(st->pos), S.sbuf);                   // a fresh image: the host has set pos to the first word after the tables
     auto next_word = [&]() { const uint32_t lo = sw.next(); return lo | (sw.next() << 8); };
@@ -1024,7 +1137,7 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restri
     if (i0 == 0) { rans.x = next_word() << 16; rans.x |= next_word(); }
     else rans.x = st->lo;
     int stop = kRunning, at;
-    if (3 * rs <= dyn_bytes) at = qdecode_rows<true>(S, rows, J, rs, i0, i1, sw, rans, final_, row_need, stop);
+    if (3 * rs + 4 <= dyn_bytes) at = qdecode_rows<true>(S, rows, J, rs, i0, i1, sw, rans, final_, row_need, stop);
     else at = qdecode_rows<false>(S, rows, J, rs, i0, i1, sw, rans, final_, row_need, stop);
     wave_sync();
     if (stop == kFailed || sw.dry) { if (lane == 0) st->status = kFailed; return; }
@@ -1101,11 +1214,12 @@ constexpr int lds_room(size_t static_lds) { return int(kLdsBudget - static_lds -
 bool serial_model_rows_fit(int w) { return 3 * ((w + 15) & ~15) <= lds_room(sizeof(ModelLds)); }
 
 template <class K>
-static bool launch_rows(K kernel, size_t static_lds, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s, int threads = 64) {
+static bool launch_rows(K kernel, size_t static_lds, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s, int threads = 64,
+                        int row_pad = 0) {
     int max_w = 1;
     for (int k = 0; k < n; k++) max_w = h_jobs[k].w > max_w ? h_jobs[k].w : max_w;
     const int room = lds_room(static_lds);
-    int dyn = 3 * ((max_w + 15) & ~15);
+    int dyn = 3 * ((max_w + row_pad + 15) & ~15) + (row_pad ? 4 : 0);
     if (dyn > room) dyn = room;                  // wider images fall back to taps from memory (the kernel compares per job)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) return false;
     hipLaunchKernelGGL(kernel, dim3(unsigned(n)), dim3(unsigned(threads)), size_t(dyn), s, d_jobs, dyn);
@@ -1138,7 +1252,7 @@ bool serial_decode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int 
 
 bool serial_qdecode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
     if (n <= 0) return true;
-    return launch_rows(k_serial_qdecode, sizeof(QDecodeLds), d_jobs, h_jobs, n, s);
+    return launch_rows(k_serial_qdecode, sizeof(QDecodeLds), d_jobs, h_jobs, n, s, 64, kQRowPad);
 }
 
 }  // namespace nblic
