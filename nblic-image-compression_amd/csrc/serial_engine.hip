@@ -122,6 +122,7 @@ struct LsqLds {
     int xch[3], bias_pub;                    // two-wave solve: the second wave's prediction / verdict / "redo with integers"; the regularisation strength for it
     i64 Mi[lsq::kMaxN][lsq::kMaxN + 1];      // integer redo of a pixel (rare): augmented system, terms
     i64 termi[lsq::kMaxN];
+    int8_t dump[64];                         // lane-parallel front: where the lanes without a regressor store theirs
 };
 struct ModelLds {
     int ctx[kContexts];
@@ -555,6 +556,170 @@ struct TapWindow {
     }
 };
 
+// ---- the pixel's model spread over the lanes (rows >= 2 of an image whose rows fit in LDS) ---------
+// Every cost of the seven-direction predictor, every term of the activity and every comparison of the context address
+// has the shape  2 X - Y - Z  over the taps (|a - e| is |2a - e - e| / 2; tap f is 2f - f - 0), so a lane takes ONE term:
+// its three operands come from the rows above in LDS at the lane's own offsets (read a pixel ahead; the rows carry two
+// columns of margin with the edge pixel repeated, which IS the reference's fall-back chain for rows >= 2, NBLIC.c:287-304
+// / QNBLIC.c:48-79), the two taps of the row being coded (a, e) are added in from registers, and what took ~250 scalar
+// instructions per pixel is
+//   lanes  0..27  the 7 x 4 cost terms (direction d in quad d): one absolute difference, two quad adds, a minimum
+//                 over keys (cost << 3 | direction: the first minimum wins, NBLIC.c:347-353) and a sum over the rows;
+//   lanes 28..33  the six terms of the activity (NBLIC.c:376), twice their value, in quads 7 and 8;
+//   lanes 36..43  the eight comparison values of the context address (NBLIC.c:398-410), bit 0 first, compared with the
+//                 prediction in one instruction whose lane mask IS the address byte;
+//   lanes 44..53  (NBLIC) the ten regressors of the least squares (NBLIC.c:164-183): each lane writes its own byte;
+// the thresholds of QNBLIC's level (11) and of the blend weight (7 / 8) are compared lane-wise too and counted with s_bcnt1.
+enum QTap : int8_t { qZ, qA, qE, qB, qC, qD, qQ, qT, qF, qG, qH, qR, qS };
+struct QLaneConst {
+    int8_t sel[3], dx[3];                    // X, Y, Z: 0 the zero byte / 1 row i-1 / 2 row i-2, and the column offset
+    int8_t a2, ce, sh;                       // + a2 * a into 2X; + ce * e into Y + Z; the prediction is shifted left by sh for the comparison
+    int8_t ca, cb, cc, cd;                   // lanes 0..6: the direction's extrapolation  ca a + cb b + cc c + cd d  (twice the neighbour)
+    int8_t dst;                              // lanes 44..53 (NBLIC): the regressor the lane holds (V / 2), -1 elsewhere
+    int16_t thr_level, thr_weight;           // lanes 0..10 / 0..7 (0x7FFF elsewhere)
+    int32_t key_or, sum_and;                 // lanes 0..27: direction / all ones; elsewhere 0x7FFFFFFF / 0
+};
+struct QLaneTable { QLaneConst l[64]; };
+constexpr int kRowPad = 8;                   // a row's margins in LDS: 2 columns left (behind 4 bytes, the first of them zero, in front of row 0), >= 4 right
+constexpr QLaneTable make_lanes(bool q) {    // q: QNBLIC (effort 0), else NBLIC
+    constexpr QTap terms[36][3] = {
+        {qA, qE, qE}, {qC, qQ, qQ}, {qB, qC, qC}, {qD, qB, qB},          // west        2 (|a-e| + |c-q| + |b-c| + |d-b|)
+        {qA, qC, qC}, {qC, qH, qH}, {qB, qF, qF}, {qD, qG, qG},          // north
+        {qA, qQ, qQ}, {qC, qS, qS}, {qB, qH, qH}, {qD, qF, qF},          // north-west
+        {qA, qB, qB}, {qC, qF, qF}, {qB, qG, qG}, {qD, qR, qR},          // north-east
+        {qA, qE, qQ}, {qC, qQ, qS}, {qB, qC, qH}, {qD, qB, qF},          // between west and north-west
+        {qA, qQ, qC}, {qC, qS, qH}, {qB, qH, qF}, {qD, qF, qG},          // between north-west and north
+        {qA, qC, qB}, {qC, qH, qF}, {qB, qF, qG}, {qD, qG, qR},          // between north and north-east
+        {qA, qE, qE}, {qB, qC, qC}, {qB, qD, qD}, {qA, qC, qC},          // activity
+        {qB, qF, qF}, {qD, qG, qG}, {qZ, qZ, qZ}, {qZ, qZ, qZ}};
+    // comparison values, bit 0 first; a and e alone are compared as 2a / 2e with twice the prediction (qA, qZ, qZ / ce = -2)
+    constexpr QTap cmp_q[8][3] = {{qB, qF, qZ}, {qA, qE, qZ}, {qF, qF, qZ}, {qE, qZ, qZ}, {qD, qD, qZ}, {qC, qC, qZ}, {qB, qB, qZ}, {qA, qZ, qZ}};
+    constexpr QTap cmp_n[8][3] = {{qA, qZ, qZ}, {qB, qB, qZ}, {qC, qC, qZ}, {qD, qD, qZ}, {qE, qZ, qZ}, {qF, qF, qZ}, {qA, qE, qZ}, {qB, qF, qZ}};
+    constexpr QTap regress[10] = {qA, qB, qC, qD, qE, qF, qT, qH, qQ, qG};
+    constexpr int8_t row_of[13] = {0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2};   // Z A E B C D Q T F G H R S
+    constexpr int8_t col_of[13] = {0, 0, 0, 0, -1, 1, -2, 2, 0, 1, -1, 2, -2};
+    constexpr int8_t ang[7][4] = {{2, 0, 0, 0}, {0, 2, 0, 0}, {0, 0, 2, 0}, {0, 0, 0, 2}, {1, 0, 1, 0}, {0, 1, 1, 0}, {0, 1, 0, 1}};
+    constexpr int16_t levels[11] = {1, 2, 4, 6, 9, 15, 25, 39, 63, 101, 151};
+    constexpr int16_t weights_q[8] = {5, 12, 34, 78, 194, 431, 601, 0x7FFF};
+    constexpr int16_t weights_n[8] = {31, 93, 279, 620, 1550, 3410, 9300, 24800};
+    QLaneTable t{};
+    for (int k = 0; k < 64; k++) {
+        QLaneConst &c = t.l[k];
+        QTap x[3] = {qZ, qZ, qZ};
+        if (k < 36) for (int o = 0; o < 3; o++) x[o] = terms[k][o];
+        else if (k < 44) for (int o = 0; o < 3; o++) x[o] = q ? cmp_q[k - 36][o] : cmp_n[k - 36][o];
+        else if (k < 54 && !q) x[0] = regress[k - 44];
+        c.dst = (k >= 44 && k < 54 && !q) ? int8_t(k - 44) : int8_t(-1);
+        const bool doubled = k >= 36 && x[1] == qZ;                      // the lane's value is 2 * tap
+        for (int o = 0; o < 3; o++) {
+            QTap tap = x[o];
+            if (o == 0 && tap == qA) { c.a2 = 2; tap = qZ; }
+            if (o == 0 && tap == qE) { c.ce = -2; tap = qZ; }            // 2e = 0 - (-2e)
+            if (o > 0 && tap == qE) { c.ce += 1; tap = qZ; }
+            c.sel[o] = row_of[tap]; c.dx[o] = col_of[tap];
+        }
+        c.sh = (doubled && k < 44) ? 1 : 0;
+        if (k < 7) { c.ca = ang[k][0]; c.cb = ang[k][1]; c.cc = ang[k][2]; c.cd = ang[k][3]; }
+        c.thr_level = k < 11 ? levels[k] : int16_t(0x7FFF);
+        c.thr_weight = k < 8 ? (q ? weights_q[k] : weights_n[k]) : int16_t(0x7FFF);
+        c.key_or = k < 28 ? k >> 2 : 0x7FFFFFFF;
+        c.sum_and = k < 28 ? -1 : 0;
+    }
+    return t;
+}
+__device__ const QLaneTable kQLanes = make_lanes(true);
+__device__ const QLaneTable kNLanes = make_lanes(false);
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) {          // full rate; v_mul_lo_u32 is a quarter of it
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int min_u(int a, int b) { return int(unsigned(a) < unsigned(b) ? unsigned(a) : unsigned(b)); }
+
+// The NBLIC front of a pixel on the lanes: taps, regressors, activity, predictor, context address.
+struct LaneFront {
+    QLaneConst lc;
+    const uint8_t *pX, *pY, *pZ;
+    int8_t *pR;                              // where the lane's regressor byte goes (a dump byte for the other lanes)
+    int stX, stY, stZ;
+    int X, Y, Z, Xn, Yn, Zn;
+    int a, e;                                // the two taps of the row being coded (uniform)
+    int V, Q;                                // the lane's 2X - Y - Z; its quad's sum of |V|
+    __device__ __forceinline__ void init(int lane, LsqLds *q) {
+        lc = kNLanes.l[lane];
+        pR = q ? (lc.dst >= 0 ? &q->vn8[lc.dst] : &q->dump[lane]) : nullptr;
+    }
+    // rows: the ring's base (pixel 0 of slot 0); r1 / r2: rows i-1 / i-2
+    __device__ __forceinline__ void row_start(uint8_t *rows, uint8_t *r1, uint8_t *r2, int w, int lane) {
+        if (lane < 8) {                                                  // the edge pixels, two columns out
+            uint8_t *r = lane < 4 ? r1 : r2;
+            const int k = lane & 3;
+            r[k < 2 ? -1 - k : w + k - 2] = r[k < 2 ? 0 : w - 1];
+        }
+        wave_sync();
+        const uint8_t *zero = rows - 4;
+        pX = lc.sel[0] == 0 ? zero : (lc.sel[0] == 1 ? r1 : r2) + lc.dx[0];
+        pY = lc.sel[1] == 0 ? zero : (lc.sel[1] == 1 ? r1 : r2) + lc.dx[1];
+        pZ = lc.sel[2] == 0 ? zero : (lc.sel[2] == 1 ? r1 : r2) + lc.dx[2];
+        stX = lc.sel[0] != 0; stY = lc.sel[1] != 0; stZ = lc.sel[2] != 0;
+        a = r1[0]; e = a;                                                // NBLIC.c:287-304 at column 0: a = b, e = a
+        Xn = *pX; Yn = *pY; Zn = *pZ;
+    }
+    __device__ __forceinline__ void begin(int) {
+        X = Xn; Y = Yn; Z = Zn;
+        pX += stX; pY += stY; pZ += stZ;
+        Xn = *pX; Yn = *pY; Zn = *pZ;                                    // the next pixel's operands
+        const int s_yz = __mul24(e, int(lc.ce)) + (Y + Z);
+        V = (X << 1) + __mul24(a, int(lc.a2)) - s_yz;
+        Q = V < 0 ? -V : V;
+        Q += dpp_i32<kQuadX1>(Q); Q += dpp_i32<kQuadX2>(Q);
+    }
+    __device__ __forceinline__ void regressors() const { *pR = int8_t((V >> 1) - kMid); }
+    __device__ __forceinline__ int activity(int err) const {
+        return ((__builtin_amdgcn_readlane(Q, 28) + __builtin_amdgcn_readlane(Q, 32)) >> 1) + 2 * iabs(err);
+    }
+    __device__ __forceinline__ int predict() const {                     // model.h predict
+        const int b = __builtin_amdgcn_readlane(X, 2), c = __builtin_amdgcn_readlane(X, 1), d = __builtin_amdgcn_readlane(X, 3);
+        const int f = __builtin_amdgcn_readlane(Y, 6);
+        int key = (Q << 3) | lc.key_or, sum = Q & lc.sum_and;
+        key = min_u(key, dpp_i32<kRor4>(key)); key = min_u(key, dpp_i32<kRor8>(key));
+        sum += dpp_i32<kRor4>(sum); sum += dpp_i32<kRor8>(sum);
+        const int k_min = min_u(__builtin_amdgcn_readlane(key, 0), __builtin_amdgcn_readlane(key, 16));
+        const int total = __builtin_amdgcn_readlane(sum, 0) + __builtin_amdgcn_readlane(sum, 16);
+        const int best = k_min >> 3, dir = k_min & 7;
+        const int spread = total - 7 * best;
+        const int wt = __builtin_popcountll(__ballot(int(lc.thr_weight) <= spread));
+        const int angv = __mul24(a, int(lc.ca)) + __mul24(b, int(lc.cb)) + __mul24(c, int(lc.cc)) + __mul24(d, int(lc.cd));
+        const int ang = __builtin_amdgcn_readlane(angv, dir);
+        const int lin = __builtin_amdgcn_readfirstlane(iclip(9 * (a + b) + 2 * (d - c) - e - f, 0, 16 * kMaxVal));
+        return (8 * wt * ang + (8 - wt) * lin + 64) >> 7;
+    }
+    __device__ __forceinline__ int context(int qu, int px0) const {      // model.h context_address
+        return ((qu >> 1) << 8) | int((__ballot((px0 << int(lc.sh)) > V) >> 36) & 0xFFull);
+    }
+    __device__ __forceinline__ void advance(int j, int xr) { e = j >= 1 ? a : xr; a = xr; }
+};
+
+// The same interface on one lane's registers (rows 0 and 1; images whose rows do not fit in LDS)
+template <bool CACHED, class Pix>
+struct ScalarFront {
+    Pix pix;
+    const uint8_t *r1, *r2;
+    int w, i;
+    TapWindow tw;
+    Taps t;
+    int8_t *vn8;
+    __device__ __forceinline__ void begin(int j) { t = CACHED ? tw.taps(w, i, j) : sample_taps(pix, w, i, j); }
+    __device__ __forceinline__ void regressors() const { store_regressors(vn8, t); }
+    __device__ __forceinline__ int activity(int err) const { return nblic::activity(t, err); }
+    __device__ __forceinline__ int predict() const { return nblic::predict(t); }
+    __device__ __forceinline__ int context(int qu, int px0) const { return context_address(t, qu, px0); }
+    __device__ __forceinline__ void advance(int j, int xr) { if (CACHED) tw.advance(r1, r2, w, j, xr); }
+};
+
 // ---- encoder: the serial model stage (prediction, context bias, quantisation) ------------------
 // CACHED: the three rows the taps can touch live in LDS (a ring, row r at r % 3), so a pixel's twelve
 // taps are twelve LDS reads issued together; otherwise (rows wider than the LDS left over) they come
@@ -731,6 +896,8 @@ __device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const Se
     const auto out = gp(J.recon);
     LsqWalk<N> lw;
     if constexpr (N > 0) lw.init(J.stats, w, lane, 0, bias_io);
+    LaneFront lf;
+    lf.init(lane, &S.q);
     uint32_t lo = cs[0], hi = cs[1], window = cs[2];
     if (CACHED && i0 > 0) {                                              // resuming: the two rows above come back from the decoded plane
         for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
@@ -753,23 +920,22 @@ __device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const Se
         if constexpr (N > 0) lw.row_begin(S.q);
         int err = 0;
         const size_t row_at = size_t(i) * size_t(w);
-        TapWindow tw;
-        if (CACHED) tw.row_start(r0, r1, r2, w);
+        auto run_row = [&](auto &front) {
         for (int j = 0; j < w; j++) {
-            const Taps t = CACHED ? tw.taps(w, i, j) : sample_taps(pix, w, i, j);
+            front.begin(j);
             int px0, p1_used = 0;
             if constexpr (N > 0) {
-                store_regressors(S.q.vn8, t);
+                front.regressors();
                 wave_sync();
                 lw.predict(S.q, j);
                 if (lw.ok1) { px0 = (lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1; p1_used = lw.p1; }
-                else { px0 = predict(t); p1_used = px0 << lsq::kFb1; }
+                else { px0 = front.predict(); p1_used = px0 << lsq::kFb1; }
             } else {
-                px0 = predict(t);
+                px0 = front.predict();
             }
-            const int delta = activity(t, err);
+            const int delta = front.activity(err);
             const Level L = level_from(S.qlut[delta < 200 ? delta : 200]);
-            const int adr = context_address(t, L.qu, px0);
+            const int adr = front.context(L.qu, px0);
             const int v = S.ctx[adr];
             const int sign = bias_sign(v), px = bias_apply(v, px0);
             const int mk = px * 2 + sign;
@@ -797,7 +963,7 @@ __device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const Se
                 }
                 return bin;
             });
-            if (sw.dry | damaged) break;                                 // the image cannot be finished from here: no pixel is written for this symbol
+            if (sw.dry | damaged) return;                                // the image cannot be finished from here: no pixel is written for this symbol
             const int y = z < kMapSyms ? int(S.sym_at[mk][z]) : z;
             if (y < kMapSyms) {                                          // NBLIC.c:497-523 (z is y's rank)
                 const int c = S.count[mk][z] + 1;
@@ -811,16 +977,26 @@ __device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const Se
                     S.count[mk][z] = c;
                 }
             }
-            const int xr = symbol_to_pixel(y, px, sign, np);
+            const int xr = __builtin_amdgcn_readfirstlane(symbol_to_pixel(y, px, sign, np));
             err = clip_err(xr, px0);
             S.ctx[adr] = bias_update(v, err);
-            if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else { out[row_at + j] = uint8_t(xr); __threadfence_block(); }
+            if (CACHED) r0[j] = uint8_t(xr); else { out[row_at + j] = uint8_t(xr); __threadfence_block(); }
+            front.advance(j, xr);
             if constexpr (N > 0) {
                 S.q.vn8[15] = int8_t(xr - kMid);
                 wave_sync();
                 lw.update(S.q, j, xr, p1_used);
                 wave_sync();
             }
+        }
+        };
+        if (CACHED && i >= 2) {
+            lf.row_start(rows, r1, r2, w, lane);
+            run_row(lf);
+        } else {
+            ScalarFront<CACHED, decltype(pix)> sf{pix, r1, r2, w, i, TapWindow{}, Taps{}, S.q.vn8};
+            if (CACHED) sf.tw.row_start(r0, r1, r2, w);
+            run_row(sf);
         }
         if (sw.dry | damaged) { stop = (damaged || final_) ? kFailed : kStarvedMidRow; break; }
         if (CACHED) {
@@ -836,7 +1012,8 @@ __device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const Se
 template <int N>
 __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restrict__ jobs, int dyn_bytes) {
     __shared__ DecodeLds S;
-    extern __shared__ __align__(16) uint8_t rows[];
+    extern __shared__ __align__(16) uint8_t rows_raw[];
+    uint8_t *rows = rows_raw + 4;                                        // serial_engine.h row_stride: margins for the lane-parallel front
     const SerialJob &J = jobs[blockIdx.x];
     const auto st = gp(J.state);
     const auto st_tab = gp(reinterpret_cast<uint32_t *>(J.state + 1));
@@ -874,10 +1051,11 @@ __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restric
         sw.start(J.stream, avail, size_t(st->pos), S.sbuf);
         cs[0] = st->lo; cs[1] = st->hi; cs[2] = st->window; bias = st->bias;
     }
-    const int rs = (J.w + 15) & ~15;
+    const int rs = (J.w + kRowPad + 15) & ~15;
+    if (lane < 4) rows_raw[lane] = 0;
     int stop = kRunning, at;
     if (sw.dry) { stop = kFailed; at = i0; }                             // a final stream shorter than its own start
-    else if (3 * rs <= dyn_bytes) at = decode_body<N, true>(S, rows, J, rs, i0, i1, sw, cs, bias, final_, stop);
+    else if (3 * rs + 4 <= dyn_bytes) at = decode_body<N, true>(S, rows, J, rs, i0, i1, sw, cs, bias, final_, stop);
     else at = decode_body<N, false>(S, rows, J, rs, i0, i1, sw, cs, bias, final_, stop);
     wave_sync();
     if (stop == kFailed || stop == kStarvedMidRow) { if (lane == 0) st->status = stop; return; }
@@ -903,70 +1081,6 @@ struct QDecodeLds {
     uint8_t coarse[12][256];
     uint32_t sbuf[256];
 };
-
-// ---- the pixel's model spread over the lanes (rows >= 2 of an image whose rows fit in LDS) ---------
-// Every cost of the seven-direction predictor, every term of the activity and every comparison of the context address
-// has the shape  2 X - Y - Z  over the taps (|a - e| is |2a - e - e| / 2; tap f is 2f - f - 0), so a lane takes ONE term:
-// its three operands come from the rows above in LDS at the lane's own offsets (read a pixel ahead), the two taps of the
-// row being decoded (a, e) are added in from registers, and what took ~250 scalar instructions per pixel is
-//   lanes  0..27  the 7 x 4 cost terms (direction d in quad d): one absolute difference, two quad adds, a minimum
-//                 over keys (cost << 3 | direction: the first minimum wins, QNBLIC.c:128-143) and a sum over the rows;
-//   lanes 28..33  the six terms of the activity (QNBLIC.c:152-161), twice their value, in quads 7 and 8;
-//   lanes 36..43  the eight comparison values of the context address (QNBLIC.c:164-173), bit 0 first, compared with
-//                 the prediction in one instruction whose lane mask IS the address byte;
-// the thresholds of the level (11) and of the blend weight (7) are compared lane-wise too and counted with s_bcnt1.
-enum QTap : int8_t { qZ, qA, qE, qB, qC, qD, qQ, qF, qG, qH, qR, qS };
-struct QLaneConst {
-    int8_t sel[3], dx[3];                    // X, Y, Z: 0 the zero byte / 1 row i-1 / 2 row i-2, and the column offset
-    int8_t a2, ce, sh;                       // + a2 * a into 2X; + ce * e into Y + Z; the prediction is shifted left by sh for the comparison
-    int8_t ca, cb, cc, cd;                   // lanes 0..6: the direction's extrapolation  ca a + cb b + cc c + cd d  (twice the neighbour)
-    int16_t thr_level, thr_weight;           // lanes 0..10 / 0..6 (0x7FFF elsewhere)
-    int32_t key_or, sum_and;                 // lanes 0..27: direction / all ones; elsewhere 0x7FFFFFFF / 0
-};
-struct QLaneTable { QLaneConst l[64]; };
-constexpr int kQRowPad = 8;                  // a row's margins in LDS: 2 columns left, >= 4 right (+ rounding to 16)
-constexpr QLaneTable make_qlanes() {
-    constexpr QTap terms[44][3] = {
-        {qA, qE, qE}, {qC, qQ, qQ}, {qB, qC, qC}, {qD, qB, qB},          // west        2 (|a-e| + |c-q| + |b-c| + |d-b|)
-        {qA, qC, qC}, {qC, qH, qH}, {qB, qF, qF}, {qD, qG, qG},          // north
-        {qA, qQ, qQ}, {qC, qS, qS}, {qB, qH, qH}, {qD, qF, qF},          // north-west
-        {qA, qB, qB}, {qC, qF, qF}, {qB, qG, qG}, {qD, qR, qR},          // north-east
-        {qA, qE, qQ}, {qC, qQ, qS}, {qB, qC, qH}, {qD, qB, qF},          // between west and north-west
-        {qA, qQ, qC}, {qC, qS, qH}, {qB, qH, qF}, {qD, qF, qG},          // between north-west and north
-        {qA, qC, qB}, {qC, qH, qF}, {qB, qF, qG}, {qD, qG, qR},          // between north and north-east
-        {qA, qE, qE}, {qB, qC, qC}, {qB, qD, qD}, {qA, qC, qC},          // activity
-        {qB, qF, qF}, {qD, qG, qG}, {qZ, qZ, qZ}, {qZ, qZ, qZ},
-        {qB, qF, qZ}, {qA, qE, qZ}, {qF, qF, qZ}, {qZ, qZ, qZ},          // 2b - f, 2a - e, f, e (2e against twice the prediction)
-        {qD, qD, qZ}, {qC, qC, qZ}, {qB, qB, qZ}, {qA, qZ, qZ}};         // d, c, b, a (2a against twice the prediction)
-    constexpr int8_t row_of[12] = {0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2};   // Z A E B C D Q F G H R S
-    constexpr int8_t col_of[12] = {0, 0, 0, 0, -1, 1, -2, 0, 1, -1, 2, -2};
-    constexpr int8_t ang[7][4] = {{2, 0, 0, 0}, {0, 2, 0, 0}, {0, 0, 2, 0}, {0, 0, 0, 2}, {1, 0, 1, 0}, {0, 1, 1, 0}, {0, 1, 0, 1}};
-    constexpr int16_t levels[11] = {1, 2, 4, 6, 9, 15, 25, 39, 63, 101, 151};
-    constexpr int16_t weights[7] = {5, 12, 34, 78, 194, 431, 601};
-    QLaneTable t{};
-    for (int k = 0; k < 64; k++) {
-        QLaneConst &c = t.l[k];
-        for (int o = 0; o < 3; o++) {
-            const QTap tap = k < 44 ? terms[k][o] : qZ;
-            c.sel[o] = row_of[tap]; c.dx[o] = col_of[tap];
-            if (o == 0 && tap == qA) c.a2 = 2;
-            if (o > 0 && tap == qE) c.ce += 1;
-        }
-        if (k == 39) { c.ce = -2; c.sh = 1; }
-        if (k == 43) c.sh = 1;
-        if (k < 7) { c.ca = ang[k][0]; c.cb = ang[k][1]; c.cc = ang[k][2]; c.cd = ang[k][3]; }
-        c.thr_level = k < 11 ? levels[k] : int16_t(0x7FFF);
-        c.thr_weight = k < 7 ? weights[k] : int16_t(0x7FFF);
-        c.key_or = k < 28 ? k >> 2 : 0x7FFFFFFF;
-        c.sum_and = k < 28 ? -1 : 0;
-    }
-    return t;
-}
-__device__ const QLaneTable kQLanes = make_qlanes();
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
-__device__ __forceinline__ int min_u(int a, int b) { return int(unsigned(a) < unsigned(b) ? unsigned(a) : unsigned(b)); }
 
 // What a pixel costs here is the chain  rANS state -> symbol -> pixel -> error -> (next pixel's level) -> ...  with a
 // dependent LDS round trip (~64 cycles) at every table lookup, and the ~200 instructions of the predictor next to it.
@@ -1036,16 +1150,16 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
                 r[k < 2 ? -1 - k : w + k - 2] = r[k < 2 ? 0 : w - 1];
             }
             wave_sync();
-            const int base1 = int(r1 - rows), base2 = int(r2 - rows);
-            int adX = lc.sel[0] == 0 ? -4 : (lc.sel[0] == 1 ? base1 : base2) + lc.dx[0];
-            int adY = lc.sel[1] == 0 ? -4 : (lc.sel[1] == 1 ? base1 : base2) + lc.dx[1];
-            int adZ = lc.sel[2] == 0 ? -4 : (lc.sel[2] == 1 ? base1 : base2) + lc.dx[2];
+            const uint8_t *zero = rows - 4;
+            const uint8_t *pX = lc.sel[0] == 0 ? zero : (lc.sel[0] == 1 ? r1 : r2) + lc.dx[0];
+            const uint8_t *pY = lc.sel[1] == 0 ? zero : (lc.sel[1] == 1 ? r1 : r2) + lc.dx[1];
+            const uint8_t *pZ = lc.sel[2] == 0 ? zero : (lc.sel[2] == 1 ? r1 : r2) + lc.dx[2];
             const int stX = lc.sel[0] != 0, stY = lc.sel[1] != 0, stZ = lc.sel[2] != 0;
             int a = r1[0], e = a;                                         // the window hands on row i-1's first pixel
-            int X = rows[adX], Y = rows[adY], Z = rows[adZ];
+            int X = *pX, Y = *pY, Z = *pZ;
             for (int j = 0; j < w; j++) {
-                adX += stX; adY += stY; adZ += stZ;
-                const int Xn = rows[adX], Yn = rows[adY], Zn = rows[adZ];            // the next pixel's operands
+                pX += stX; pY += stY; pZ += stZ;
+                const int Xn = *pX, Yn = *pY, Zn = *pZ;                              // the next pixel's operands
                 // everything that does not wait for the pixel on the left
                 const int s_yz = __mul24(e, int(lc.ce)) + (Y + Z);
                 const int x2 = X << 1;
@@ -1057,11 +1171,12 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
                 const int V = X2 - s_yz;
                 int Q = V < 0 ? -V : V;
                 Q += dpp_i32<kQuadX1>(Q); Q += dpp_i32<kQuadX2>(Q);                   // the quad's four terms
-                // level: the symbol search starts from it
+                // level -> first lookup of the symbol search (its round trips to LDS run under the prediction)
                 const int act = ((__builtin_amdgcn_readlane(Q, 28) + __builtin_amdgcn_readlane(Q, 32)) >> 1) + 2 * iabs(err);
                 const int qd = __builtin_popcountll(__ballot(int(lc.thr_level) <= act));
-                const int y = rans.symbol(S, qd, sw);
-                // prediction
+                const uint32_t low = rans.x & 32767u;
+                const int yc = __builtin_amdgcn_readfirstlane(S.coarse[qd][low >> 7]);
+                // prediction, first half
                 int key = (Q << 3) | lc.key_or, sum = Q & lc.sum_and;
                 key = min_u(key, dpp_i32<kRor4>(key)); key = min_u(key, dpp_i32<kRor8>(key));
                 sum += dpp_i32<kRor4>(sum); sum += dpp_i32<kRor8>(sum);
@@ -1069,17 +1184,37 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
                 const int total = __builtin_amdgcn_readlane(sum, 0) + __builtin_amdgcn_readlane(sum, 16);
                 const int best = k_min >> 3, dir = k_min & 7;
                 const int spread = (total - 7 * best) >> 3;
+                // second lookup: the slot boundaries of symbols yc, yc + 1 (and the start of yc + 2)
+                const uint32_t p0 = S.span[qd * 256 + yc], p1 = S.span[qd * 256 + yc + 1];
+                // prediction, second half
                 const int wt = __builtin_popcountll(__ballot(int(lc.thr_weight) <= spread));
                 const int ang = __builtin_amdgcn_readlane(ang_bcd + __mul24(a, int(lc.ca)), dir);
-                const int lin = iclip(9 * (a + b) + 2 * (d - c) - e - f, 0, 16 * kMaxVal);
+                const int lin = __builtin_amdgcn_readfirstlane(iclip(9 * (a + b) + 2 * (d - c) - e - f, 0, 16 * kMaxVal));
                 const int px0 = (8 * wt * ang + (8 - wt) * lin + 64) >> 7;
                 const int adr = (qd << 8) | int((__ballot((px0 << int(lc.sh)) > V) >> 36) & 0xFFull);
                 const int v = S.ctx[adr];
+                // the symbol: nearly always one of the two just read
+                const uint32_t e0 = p0 >> 16, e1 = p1 >> 16;
+                int y;
+                uint32_t s0, s1;
+                if (low < e0 || yc >= 255) { y = yc; s0 = p0 & 0xFFFFu; s1 = e0; }
+                else if (low < e1 || yc >= 254) { y = yc + 1; s0 = e0; s1 = e1; }
+                else {
+                    y = yc + 2;
+                    for (;;) {                                                       // symbols with no slots are stepped over
+                        const uint32_t q0 = S.span[qd * 256 + y];
+                        if (low < (q0 >> 16) || y >= 255) { s0 = q0 & 0xFFFFu; s1 = q0 >> 16; break; }
+                        y++;
+                    }
+                }
+                rans.x = mul_u24(rans.x >> 15, s1 - s0) + low - s0;               // < 2^17 times <= 2^15
+                if (rans.x < 65536u) { const uint32_t lo = sw.next(); rans.x = (rans.x << 16) | lo | (sw.next() << 8); }
+                // the pixel
                 const int sign = (v >> 10) & 1;
                 const int px = iclip(px0 + (v >> 11) + sign, 0, kMaxVal);
                 const int px_out = __builtin_amdgcn_readfirstlane(symbol_to_pixel(y, px, sign, 0));
                 err = px_out - px0;
-                S.ctx[adr] = (v * 128 - v + err * 2048 + 63) >> 7;
+                S.ctx[adr] = (__mul24(v, 127) + err * 2048 + 63) >> 7;
                 r0[j] = uint8_t(px_out);
                 e = a; a = px_out;
                 X = Xn; Y = Yn; Z = Zn;
@@ -1127,7 +1262,7 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restri
     wave_sync();
     // a row in LDS: two columns of margin on the left (after the four bytes in front of row 0, which hold zero for the
     // lanes without an operand) and at least four on the right -- the lane-parallel model reads the clamped columns there
-    const int rs = (w + kQRowPad + 15) & ~15;
+    const int rs = (w + kRowPad + 15) & ~15;
     uint8_t *rows = rows_raw + 4;
     if (lane < 4) rows_raw[lane] = 0;
     StreamWindow sw;
@@ -1244,15 +1379,15 @@ bool serial_model_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n
 bool serial_decode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
     if (n <= 0) return true;
     switch (h_jobs[0].effort) {
-        case 1: return launch_rows(k_serial_decode<0>, sizeof(DecodeLds), d_jobs, h_jobs, n, s);
-        case 2: return launch_rows(k_serial_decode<6>, sizeof(DecodeLds), d_jobs, h_jobs, n, s);
-        default: return launch_rows(k_serial_decode<10>, sizeof(DecodeLds), d_jobs, h_jobs, n, s);
+        case 1: return launch_rows(k_serial_decode<0>, sizeof(DecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
+        case 2: return launch_rows(k_serial_decode<6>, sizeof(DecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
+        default: return launch_rows(k_serial_decode<10>, sizeof(DecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
     }
 }
 
 bool serial_qdecode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
     if (n <= 0) return true;
-    return launch_rows(k_serial_qdecode, sizeof(QDecodeLds), d_jobs, h_jobs, n, s, 64, kQRowPad);
+    return launch_rows(k_serial_qdecode, sizeof(QDecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
 }
 
 }  // namespace nblic
