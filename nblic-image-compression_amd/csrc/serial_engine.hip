@@ -746,6 +746,8 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
     const auto pxs = gp(J.pxs);
     LsqWalk<N, WAVES> lw;
     if constexpr (N > 0) lw.init(J.stats, w, lane, wave, bias_io);
+    LaneFront lf;
+    lf.init(lane, &S.q);
     if (main && CACHED && i0 > 0) {                                      // resuming: the two rows above come back from the reconstruction
         const auto prev = J.recon ? gp(const_cast<const uint8_t *>(J.recon)) : img;      // lossless: the reconstruction IS the input
         for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
@@ -768,17 +770,16 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
         };
         if constexpr (N > 0) { if (main) lw.row_begin(S.q); }
         int err = 0;
-        TapWindow tw;
         int x_next = 0;
-        if (main && CACHED) { tw.row_start(r0, r1, r2, w); x_next = r0[0]; }
+        if (main && CACHED) x_next = r0[0];
+        auto run_row = [&](auto &front) {
         for (int j = 0; j < w; j++) {
-            Taps t{};
             int x = 0;
             if (main) {
-                t = CACHED ? tw.taps(w, i, j) : sample_taps(pix, w, i, j);
+                front.begin(j);
                 x = CACHED ? x_next : int(img[row_at + j]);
                 if (CACHED) x_next = r0[j + 1 < w ? j + 1 : j];            // the next original pixel: requested a pixel ahead
-                if constexpr (N > 0) store_regressors(S.q.vn8, t);
+                if constexpr (N > 0) front.regressors();
             }
             int px0 = 0, p1_used = 0;
             if constexpr (N > 0) {
@@ -789,20 +790,21 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
             if (main) {
                 if constexpr (N > 0) {
                     if (lw.ok1) { px0 = (lw.p1 + (1 << (lsq::kFb1 - 1))) >> lsq::kFb1; p1_used = lw.p1; }
-                    else { px0 = predict(t); p1_used = px0 << lsq::kFb1; }
+                    else { px0 = front.predict(); p1_used = px0 << lsq::kFb1; }
                 } else {
-                    px0 = predict(t);
+                    px0 = front.predict();
                 }
-                const int delta = activity(t, err);
+                const int delta = front.activity(err);
                 const Level L = level_from(S.qlut[delta < 200 ? delta : 200]);
-                const int adr = context_address(t, L.qu, px0);
+                const int adr = front.context(L.qu, px0);
                 const int v = S.ctx[adr];
                 const int sign = bias_sign(v), px = bias_apply(v, px0);
                 const int y = residual_to_symbol(x, px, sign, np);
-                xr = symbol_to_pixel(y, px, sign, np);
+                xr = __builtin_amdgcn_readfirstlane(symbol_to_pixel(y, px, sign, np));
                 err = clip_err(xr, px0);
                 S.ctx[adr] = bias_update(v, err);
-                if (CACHED) { r0[j] = uint8_t(xr); tw.advance(r1, r2, w, j, xr); } else { recon[row_at + j] = uint8_t(xr); __threadfence_block(); }
+                if (CACHED) r0[j] = uint8_t(xr); else { recon[row_at + j] = uint8_t(xr); __threadfence_block(); }
+                front.advance(j, xr);
                 S.rec_ring[j & 63] = pack_s1(px0, adr, L);
                 S.pxs_ring[j & 63] = uint16_t(px | (sign << 8));
                 if ((j & 63) == 63 || j == w - 1) {                      // a lane per record: coalesced stores
@@ -820,6 +822,15 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
                 }
             }
         }
+        };
+        if (CACHED && i >= 2) {
+            if (main) lf.row_start(rows, r1, r2, w, lane);
+            run_row(lf);
+        } else {
+            ScalarFront<CACHED, decltype(pix)> sf{pix, r1, r2, w, i, TapWindow{}, Taps{}, S.q.vn8};
+            if (main && CACHED) sf.tw.row_start(r0, r1, r2, w);
+            run_row(sf);
+        }
         if (main && CACHED && J.recon) {
             wave_sync();
             for (int c = lane; c < w; c += 64) recon[row_at + c] = r0[c];
@@ -831,7 +842,8 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
 template <int N, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) k_serial_model(const SerialJob *__restrict__ jobs, int dyn_bytes) {
     __shared__ ModelLds S;
-    extern __shared__ __align__(16) uint8_t rows[];
+    extern __shared__ __align__(16) uint8_t rows_raw[];
+    uint8_t *rows = rows_raw + 4;                                        // margins for the lane-parallel front (kRowPad)
     const SerialJob &J = jobs[blockIdx.x];
     const auto st = gp(J.state);
     const auto st_ctx = gp(reinterpret_cast<int *>(J.state + 1));
@@ -843,9 +855,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_serial_model(const SerialJob *__
     for (int k = tid; k < kContexts; k += 64 * WAVES) S.ctx[k] = i0 ? st_ctx[k] : 0;
     if (tid < 64) fill_qlut(S.qlut);
     if (tid < 16) S.q.vn8[tid] = 0;
+    if (tid < 4) rows_raw[tid] = 0;
     if (WAVES == 2) block_sync(); else wave_sync();
-    const int rs = (J.w + 15) & ~15;
-    if (3 * rs <= dyn_bytes) model_body<N, true, WAVES>(S, rows, J, rs, i0, i1, bias);
+    const int rs = (J.w + kRowPad + 15) & ~15;
+    if (3 * rs + 4 <= dyn_bytes) model_body<N, true, WAVES>(S, rows, J, rs, i0, i1, bias);
     else model_body<N, false, WAVES>(S, rows, J, rs, i0, i1, bias);
     if (WAVES == 2) block_sync(); else wave_sync();
     if (i1 < J.h) for (int k = tid; k < kContexts; k += 64 * WAVES) st_ctx[k] = S.ctx[k];
@@ -1346,7 +1359,7 @@ constexpr int kLdsBudget = 160 * 1024;
 constexpr int kTwoWaveImages = 64;               // effort-3 launches of at most this many images give every image a second wave
 constexpr int lds_room(size_t static_lds) { return int(kLdsBudget - static_lds - 256) & ~15; }
 
-bool serial_model_rows_fit(int w) { return 3 * ((w + 15) & ~15) <= lds_room(sizeof(ModelLds)); }
+bool serial_model_rows_fit(int w) { return 3 * ((w + kRowPad + 15) & ~15) + 4 <= lds_room(sizeof(ModelLds)); }
 
 template <class K>
 static bool launch_rows(K kernel, size_t static_lds, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s, int threads = 64,
@@ -1354,7 +1367,7 @@ static bool launch_rows(K kernel, size_t static_lds, const SerialJob *d_jobs, co
     int max_w = 1;
     for (int k = 0; k < n; k++) max_w = h_jobs[k].w > max_w ? h_jobs[k].w : max_w;
     const int room = lds_room(static_lds);
-    int dyn = 3 * ((max_w + row_pad + 15) & ~15) + (row_pad ? 4 : 0);
+    int dyn = 3 * ((max_w + row_pad + 15) & ~15) + (row_pad ? 4 : 0);   // the kernels' row ring: rows_raw + 4, stride (w + kRowPad + 15) & ~15
     if (dyn > room) dyn = room;                  // wider images fall back to taps from memory (the kernel compares per job)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) return false;
     hipLaunchKernelGGL(kernel, dim3(unsigned(n)), dim3(unsigned(threads)), size_t(dyn), s, d_jobs, dyn);
@@ -1364,15 +1377,15 @@ static bool launch_rows(K kernel, size_t static_lds, const SerialJob *d_jobs, co
 bool serial_model_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
     if (n <= 0) return true;
     switch (h_jobs[0].effort) {
-        case 1: return launch_rows(k_serial_model<0, 1>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
-        case 2: return launch_rows(k_serial_model<6, 1>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
+        case 1: return launch_rows(k_serial_model<0, 1>, sizeof(ModelLds), d_jobs, h_jobs, n, s, 64, kRowPad);
+        case 2: return launch_rows(k_serial_model<6, 1>, sizeof(ModelLds), d_jobs, h_jobs, n, s, 64, kRowPad);
         default:
             // Effort 3, few images: two waves per image, a system each -- 4.39 instead of 4.5 us per pixel per image (the
             // two barriers per pixel eat two thirds of what the shorter elimination saves).  Many images: the second wave
             // would take a SIMD slot from another image for a 3 % shorter chain (2048 images: 156 against 261 Mpx/s), so
             // a batch that can fill the GPU with single waves keeps them.
-            if (n <= kTwoWaveImages) return launch_rows(k_serial_model<10, 2>, sizeof(ModelLds), d_jobs, h_jobs, n, s, 128);
-            return launch_rows(k_serial_model<10, 1>, sizeof(ModelLds), d_jobs, h_jobs, n, s);
+            if (n <= kTwoWaveImages) return launch_rows(k_serial_model<10, 2>, sizeof(ModelLds), d_jobs, h_jobs, n, s, 128, kRowPad);
+            return launch_rows(k_serial_model<10, 1>, sizeof(ModelLds), d_jobs, h_jobs, n, s, 64, kRowPad);
     }
 }
 
