@@ -118,7 +118,7 @@ __device__ __forceinline__ int prob_one(int c0, int c1) {
 // ---- LDS images --------------------------------------------------------------------------------
 struct LsqLds {
     double D[128];                           // statistics of the pixel about to be predicted: [s | b | A] (E + F)
-    int8_t vn8[16];                          // regressors 0..9 (tap - 128); [14] = 0; [15] = x' - 128
+    int8_t vn8[16];                          // regressors 0..9 (tap - 128); [14] = 0
     int xch[3], bias_pub;                    // two-wave solve: the second wave's prediction / verdict / "redo with integers"; the regularisation strength for it
     i64 Mi[lsq::kMaxN][lsq::kMaxN + 1];      // integer redo of a pixel (rare): augmented system, terms
     i64 termi[lsq::kMaxN];
@@ -378,6 +378,7 @@ struct LsqWalk {
     static constexpr int kS = L::kS;                                     // column slots per lane (lsq_solve_split)
     LsqEntries<N> en;
     double E[T::kSlots], Bj[T::kSlots], Fj[T::kSlots], Bn[T::kSlots], Fn[T::kSlots];
+    int ra[T::kSlots], rb[T::kSlots];                                    // the regressors the lane's entries multiply (read while the systems are solved)
     NB_GLOBAL double *Bst, *Fst;
     int bias, b1, b2, lane, row, cg, sys, group_base4, w;
     int d_base, d_last, diag_slot, last_kind;                            // where the lane's slots sit in S.D; which slot (if any) is on the diagonal; last slot: 0 matrix column, 1 right-hand side, 2 nothing
@@ -433,10 +434,16 @@ struct LsqWalk {
         const double p = lsq_solve_split<L>(M, row, cg, group_base4, S.vn8, g, ok);
         return p < 0.0 ? 0.0 : (p > double(kMaxVal << lsq::kFb1) ? double(kMaxVal << lsq::kFb1) : p);
     }
+    // the pixel's regressors stand in S.vn8: the lane's factors, long before update() needs them (x' itself comes in a register)
+    __device__ __forceinline__ void fetch_factors(const LsqLds &S) {
+#pragma unroll
+        for (int s = 0; s < T::kSlots; s++) { ra[s] = S.vn8[en.ia[s] == 15 ? 14 : en.ia[s]]; rb[s] = S.vn8[en.ib[s]]; }
+    }
     __device__ __forceinline__ int clamp_q12(i64 q) const { const i64 top = i64(kMaxVal) << lsq::kFb1; return int(q < 0 ? 0 : (q > top ? top : q)); }
     // WAVES = 1: both predictions of pixel j from S.D and S.vn8 (complete and synchronised)
     __device__ __forceinline__ void predict(LsqLds &S, int j) {
         load_cols(j + 1, Bn, Fn);                                         // next pixel's columns: a whole pixel ahead of their use
+        fetch_factors(S);
         lsq::bias_pair(bias, b1, b2);
         lsq::Guard g;
         int ok;
@@ -455,7 +462,7 @@ struct LsqWalk {
     // WAVES = 2: this wave's ONE system.  The main wave keeps p1 / ok1 (and redoes its system with integers at once if
     // it has to: the prediction itself depends on it); the other wave leaves prediction, verdict and "redo me" in S.xch
     __device__ __forceinline__ void solve_one(LsqLds &S, int j, bool main) {
-        if (main) load_cols(j + 1, Bn, Fn);
+        if (main) { load_cols(j + 1, Bn, Fn); fetch_factors(S); }
         lsq::bias_pair(main ? bias : S.bias_pub, b1, b2);
         lsq::Guard g;
         int ok;
@@ -475,7 +482,7 @@ struct LsqWalk {
         p2 = S.xch[0]; ok2 = S.xch[1] != 0;
         if (S.xch[2]) { i64 q2 = 0; ok2 = lsq_solve_int(S, N, b2, &q2) != 0; p2 = clamp_q12(q2); }
     }
-    // fold the coded pixel in (NBLIC.c:242-283, :882-893) and publish the next pixel's statistics; S.vn8[15] = x' - 128 is set
+    // fold the coded pixel in (NBLIC.c:242-283, :882-893) and publish the next pixel's statistics
     __device__ __forceinline__ void update(LsqLds &S, int j, int xr, int p1_used) {
         const int xq = xr << lsq::kFb1;
         const double s_curr = double(iabs(p1_used - xq));
@@ -485,7 +492,7 @@ struct LsqWalk {
         const double sw = lsq::sample_weight(s_sum), rs = lsq::recip_raw(sw);
 #pragma unroll
         for (int s = 0; s < T::kSlots; s++) {
-            const int prod = int(S.vn8[en.ia[s]]) * int(S.vn8[en.ib[s]]);
+            const int prod = (en.ia[s] == 15 ? xr - kMid : ra[s]) * rb[s];
             double sample = lsq::sample_entry(prod, en.scale[s], sw, rs);
             if (s == 0) sample = lane == 0 ? s_curr : sample;
             const double b = en.decay(Bj[s], s) + sample;
@@ -811,10 +818,9 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
                     const int base = j & ~63;
                     if (base + lane <= j) { rec1[out_at + base + lane] = S.rec_ring[lane]; pxs[out_at + base + lane] = S.pxs_ring[lane]; }
                 }
-                if constexpr (N > 0) S.q.vn8[15] = int8_t(xr - kMid);
             }
             if constexpr (N > 0) {
-                if constexpr (WAVES == 2) block_sync(); else wave_sync();
+                if constexpr (WAVES == 2) block_sync();                   // the other wave's verdict stands in S.q.xch
                 if (main) {
                     if constexpr (WAVES == 2) lw.take_other(S.q);
                     lw.update(S.q, j, xr, p1_used);
@@ -996,8 +1002,6 @@ __device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const Se
             if (CACHED) r0[j] = uint8_t(xr); else { out[row_at + j] = uint8_t(xr); __threadfence_block(); }
             front.advance(j, xr);
             if constexpr (N > 0) {
-                S.q.vn8[15] = int8_t(xr - kMid);
-                wave_sync();
                 lw.update(S.q, j, xr, p1_used);
                 wave_sync();
             }
