@@ -1219,7 +1219,7 @@ long q_decode_tables(const uint16_t *in, size_t n_words, int *h, int *w, uint32_
 
 struct DecodeItem { int k, h, w, near, k_step, effort, kind; size_t len; long q_pos; int qtab; };      // kind 0 NBLIC, 1 QNBLIC; q_pos: first rANS word; qtab: which parsed table set
 
-constexpr size_t kQTab = 2 * 12 * 256 * sizeof(uint32_t) + size_t(12) * 32768;              // QNBLIC: frequencies, cumulative starts, slot -> symbol
+constexpr size_t kQTab = 2 * 12 * 256 * sizeof(uint32_t);                                   // QNBLIC: frequencies, cumulative starts (the kernel derives its symbol index from them)
 static size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
 
 // Header of a stream of which `len` bytes are in hand (NBLIC.c:698-745, QNBLIC.c:475-486).  0 = not a stream this
@@ -1243,8 +1243,8 @@ static int parse_stream_header(const unsigned char *p, size_t len, long max_px, 
 static size_t decode_state_bytes(const DecodeItem &it) { return up256(it.kind ? kQDecodeStateBytes : kDecodeStateBytes); }
 
 // One launch round of a (codec, effort) class: every job advances by its `rows`.
-static bool decode_launch(const DecodeItem &first, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t st) {
-    return first.kind == 1 ? serial_qdecode_launch(d_jobs, h_jobs, n, st) : serial_decode_launch(d_jobs, h_jobs, n, st);
+static bool decode_launch(const DecodeItem &first, const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t st, bool whole_streams) {
+    return first.kind == 1 ? serial_qdecode_launch(d_jobs, h_jobs, n, st) : serial_decode_launch(d_jobs, h_jobs, n, st, whole_streams);
 }
 
 static bool ensure_decode_space(nblic_amd_ctx *c, size_t arena, int m) {
@@ -1277,7 +1277,7 @@ static bool decode_batch(nblic_amd_ctx *c, int n, const unsigned char *const *st
             std::vector<uint8_t> tab(kQTab);                             // do not parse is refused here and never reaches the GPU
             uint32_t *freq = reinterpret_cast<uint32_t *>(tab.data()), *start = freq + 12 * 256;
             int hh = 0, ww = 0;
-            it.q_pos = q_decode_tables(reinterpret_cast<const uint16_t *>(streams[k]), lens[k] / 2, &hh, &ww, freq, start, tab.data() + 2 * 12 * 256 * sizeof(uint32_t));
+            it.q_pos = q_decode_tables(reinterpret_cast<const uint16_t *>(streams[k]), lens[k] / 2, &hh, &ww, freq, start, nullptr);
             if (it.q_pos < 0 || size_t(it.q_pos) * 2 + 4 > lens[k]) continue;
             it.qtab = int(qtabs.size());
             qtabs.push_back(std::move(tab));
@@ -1316,7 +1316,7 @@ static bool decode_batch(nblic_amd_ctx *c, int n, const unsigned char *const *st
         if (it.kind == 1) {
             uint8_t *d_tab = c->dec_arena + off; off += up256(kQTab);
             HIP_OK(hipMemcpyAsync(d_tab, qtabs[size_t(it.qtab)].data(), kQTab, hipMemcpyHostToDevice, st));
-            J.q_freq = reinterpret_cast<const uint32_t *>(d_tab); J.q_start = J.q_freq + 12 * 256; J.q_slot = d_tab + 2 * 12 * 256 * sizeof(uint32_t);
+            J.q_freq = reinterpret_cast<const uint32_t *>(d_tab); J.q_start = J.q_freq + 12 * 256; J.q_slot = nullptr;
         }
     }
     HIP_OK(hipMemcpyAsync(c->dec_jobs, jobs.data(), size_t(m) * sizeof(SerialJob), hipMemcpyHostToDevice, st));
@@ -1326,7 +1326,7 @@ static bool decode_batch(nblic_amd_ctx *c, int n, const unsigned char *const *st
         int launches = 1;
         for (int i = i0; i < i1; i++) launches = std::max(launches, serial_launches(jobs[size_t(i)].h, jobs[size_t(i)].rows));
         for (int l = 0; l < launches; l++)
-            if (!decode_launch(items[size_t(i0)], c->dec_jobs + i0, jobs.data() + i0, i1 - i0, st)) { fprintf(stderr, "[nblic_amd] decode launch failed\n"); hipStreamSynchronize(st); return false; }
+            if (!decode_launch(items[size_t(i0)], c->dec_jobs + i0, jobs.data() + i0, i1 - i0, st, true)) { fprintf(stderr, "[nblic_amd] decode launch failed\n"); hipStreamSynchronize(st); return false; }
         c->serial_launch_count += launches;
         i0 = i1;
     }
@@ -1412,7 +1412,7 @@ static int decode_fed(nblic_amd_ctx *c, const unsigned char *p, bool qnblic, uns
     J.stream = d_stream;
     J.h = it.h; J.w = it.w; J.near = it.near; J.k_step = it.k_step; J.effort = it.effort;
     J.rows = serial_rows_per_launch(it.h, it.w, qnblic ? 1 : it.effort, c->serial_rows);
-    if (qnblic) { J.q_freq = reinterpret_cast<const uint32_t *>(d_tab); J.q_start = J.q_freq + 12 * 256; J.q_slot = d_tab + 2 * 12 * 256 * sizeof(uint32_t); }
+    if (qnblic) { J.q_freq = reinterpret_cast<const uint32_t *>(d_tab); J.q_start = J.q_freq + 12 * 256; J.q_slot = nullptr; }
     if (hipMemcpyAsync(c->dec_jobs, &J, sizeof J, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 
     std::vector<uint8_t> host;                                           // the stream as far as it has been fetched
@@ -1437,10 +1437,10 @@ static int decode_fed(nblic_amd_ctx *c, const unsigned char *p, bool qnblic, uns
         std::vector<uint8_t> tab(kQTab);
         uint32_t *freq = reinterpret_cast<uint32_t *>(tab.data()), *start = freq + 12 * 256;
         int hh = 0, ww = 0;
-        long pos = q_decode_tables(reinterpret_cast<const uint16_t *>(host.data()), host.size() / 2, &hh, &ww, freq, start, tab.data() + 2 * 12 * 256 * sizeof(uint32_t));
+        long pos = q_decode_tables(reinterpret_cast<const uint16_t *>(host.data()), host.size() / 2, &hh, &ww, freq, start, nullptr);
         if (pos < 0 && !final_ && host.size() < 65536) {                 // the tables may simply not be in hand yet
             if (!feed(65536)) return -1;
-            pos = q_decode_tables(reinterpret_cast<const uint16_t *>(host.data()), host.size() / 2, &hh, &ww, freq, start, tab.data() + 2 * 12 * 256 * sizeof(uint32_t));
+            pos = q_decode_tables(reinterpret_cast<const uint16_t *>(host.data()), host.size() / 2, &hh, &ww, freq, start, nullptr);
         }
         if (pos < 0) return -1;
         if (hipMemcpyAsync(d_tab, tab.data(), kQTab, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
@@ -1457,7 +1457,7 @@ static int decode_fed(nblic_amd_ctx *c, const unsigned char *p, bool qnblic, uns
             // header fields the host owns are rewritten; on a resumed image the kernel's own fields come back unchanged
             if (hipMemcpyAsync(J.state, &S, sizeof S, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
             for (int l = 0; l < launches; l++)                           // launches after a stop return at once
-                if (!decode_launch(it, c->dec_jobs, &J, 1, st)) return -1;
+                if (!decode_launch(it, c->dec_jobs, &J, 1, st, false)) return -1;
             c->serial_launch_count += launches;
             if (hipMemcpyAsync(&S, J.state, sizeof S, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
             if (S.status == kStarved && !final_) { if (!feed(host.size() + chunk)) return -1; continue; }

@@ -118,8 +118,7 @@ long q_entropy_encode(uint16_t *out, size_t cap_words, int h, int w, const uint1
 }
 
 // Decoder front matter (QNBLIC.c:505-518): parses the header and the twelve histograms, builds
-// freq / start (12 x 256 each) and the slot -> symbol tables (12 x 32768 bytes) for the device
-// engine.  Returns the word index where the rANS payload starts, or -1.
+// freq / start (12 x 256 each) and, when `slot` is given, the slot -> symbol tables (12 x 32768 bytes).  Returns the word index where the rANS payload starts, or -1.
 long q_decode_tables(const uint16_t *in, size_t n_words, int *h, int *w, uint32_t *freq, uint32_t *start, uint8_t *slot) {
     if (n_words < 6 || in[0] != (uint16_t)('Q' | ('0' << 8)) || in[1] != (uint16_t)('.' | ('2' << 8))) return -1;
     *h = in[2]; *w = in[3];
@@ -130,6 +129,7 @@ long q_decode_tables(const uint16_t *in, size_t n_words, int *h, int *w, uint32_
         if (!p) return -1;
         uint32_t acc = 0;
         for (int s = 0; s < kQSyms; s++) { s0[s] = acc; acc += f[s]; }
+        if (!slot) continue;                 // the device engine searches the cumulative table itself
         uint8_t *tab = slot + (size_t)k * kQNormSum;
         for (uint32_t s = 0; s + 1 < kQSyms; s++)
             for (uint32_t i = s0[s]; i < s0[s + 1] && i < kQNormSum; i++) tab[i] = (uint8_t)s;

@@ -66,7 +66,7 @@ struct SerialJob {
     int rows;                  // rows per launch (>= 1)
     int out_row0;              // encode: the row whose records sit at index 0 of rec1 / pxs (0, or the first row of the band they hold)
     // QNBLIC decode only
-    const uint32_t *q_freq, *q_start; const uint8_t *q_slot;
+    const uint32_t *q_freq, *q_start; const uint8_t *q_slot;      // 12 x 256 frequencies and cumulative starts; q_slot: unused (the kernel searches q_start)
 };
 
 constexpr int stats_stride(int effort) { return effort == 3 ? 128 : (effort == 2 ? 64 : 0); }   // doubles per pixel column per array
@@ -90,7 +90,7 @@ bool serial_model_rows_fit(int w);
 // d_jobs[0..n): all of one effort (1, 2 or 3); h_jobs: host copy, read to size the launch.  ONE launch: every job
 // advances by its `rows`; call serial_launches(h, rows) times (maximum over the jobs) to finish them.
 bool serial_model_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s);
-bool serial_decode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s);
+bool serial_decode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s, bool whole_streams);   // whole_streams: every job's stream is final (SerialState::final_)
 bool serial_qdecode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s);
 int serial_selftest(hipStream_t s);                    // device check of the double-carried divisions against 64-bit integers and of the half-wave exchange; 0 = pass
 

@@ -143,6 +143,19 @@ struct DecodeLds {
     LsqLds q;
 };
 static_assert(offsetof(DecodeLds, qlut) == kDecodeStateBytes - sizeof(SerialState), "state record = the leading tables");
+// Many images side by side: 89 KB of LDS per image is ONE wave per CU.  The lean image keeps the re-mappers' hit counts
+// (40 KB, touched twice per pixel and off the coder's chain) in the image's state record in memory -- where a resumed
+// launch keeps them anyway -- and drops the symbol -> rank table the decoder only ever writes: 38 KB, four waves per CU.
+struct DecodeLdsLean {
+    int ctx[kContexts];
+    uint32_t cnt[kLevels][kTreeNodes];
+    uint8_t sym_at[512][kMapSyms];
+    uint16_t qlut[208];
+    uint32_t sbuf[256];
+    LsqLds q;
+};
+constexpr int kRecCount = kContexts + kLevels * kTreeNodes;              // word offsets of the tables in the state record (after SerialState)
+constexpr int kRecRank = kRecCount + 512 * kMapSyms, kRecSym = kRecRank + 512 * kMapSyms / 4;
 
 // activity -> (qu, qv, qw) (model.h quantise) as a table: the interpolation divides by a level gap
 __device__ void fill_qlut(uint16_t *qlut) {
@@ -906,10 +919,16 @@ struct StreamWindow {
 
 // rows [i0, i1) of the image; coder state in / out through `cs` (lo, hi, window); returns the row it stopped in front of
 // and sets `stop` to kRunning (ran its rows), kStarved, kStarvedMidRow or kFailed
-template <int N, bool CACHED>
-__device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const SerialJob &J, const int rs, const int i0, const int i1,
+template <int N, bool CACHED, class Lds>
+__device__ __forceinline__ int decode_body(Lds &S, uint8_t *rows, const SerialJob &J, const int rs, const int i0, const int i1,
                                            StreamWindow &sw, uint32_t (&cs)[3], int &bias_io, const bool final_, int &stop) {
+    constexpr bool kLean = std::is_same<Lds, DecodeLdsLean>::value;
     const int w = J.w, lane = int(threadIdx.x), k_step = J.k_step;
+    // the re-mappers' hit counts: LDS, or the image's state record
+    auto hits = [&] {
+        if constexpr (kLean) return gp(reinterpret_cast<int *>(J.state + 1) + kRecCount);
+        else return &S.count[0][0];
+    }();
     const NearParams np = near_params(J.near);
     const uint64_t ktab = level_shift_table(k_step);
     const auto out = gp(J.recon);
@@ -985,15 +1004,16 @@ __device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const Se
             if (sw.dry | damaged) return;                                // the image cannot be finished from here: no pixel is written for this symbol
             const int y = z < kMapSyms ? int(S.sym_at[mk][z]) : z;
             if (y < kMapSyms) {                                          // NBLIC.c:497-523 (z is y's rank)
-                const int c = S.count[mk][z] + 1;
-                const int c_up = z > 0 ? S.count[mk][z - 1] : 0x7FFFFFFF;
+                const int at = mk * kMapSyms + z;
+                const int c = hits[at] + 1;
+                const int c_up = z > 0 ? hits[at - 1] : 0x7FFFFFFF;
                 if (c_up < c) {
                     const int other = S.sym_at[mk][z - 1];
-                    S.count[mk][z] = c_up; S.count[mk][z - 1] = c;
+                    hits[at] = c_up; hits[at - 1] = c;
                     S.sym_at[mk][z] = uint8_t(other); S.sym_at[mk][z - 1] = uint8_t(y);
-                    S.rank_of[mk][y] = uint8_t(z - 1); S.rank_of[mk][other] = uint8_t(z);
+                    if constexpr (!kLean) { S.rank_of[mk][y] = uint8_t(z - 1); S.rank_of[mk][other] = uint8_t(z); }
                 } else {
-                    S.count[mk][z] = c;
+                    hits[at] = c;
                 }
             }
             const int xr = __builtin_amdgcn_readfirstlane(symbol_to_pixel(y, px, sign, np));
@@ -1026,9 +1046,10 @@ __device__ __forceinline__ int decode_body(DecodeLds &S, uint8_t *rows, const Se
     return i;
 }
 
-template <int N>
+template <int N, bool LEAN>
 __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restrict__ jobs, int dyn_bytes) {
-    __shared__ DecodeLds S;
+    using Lds = typename std::conditional<LEAN, DecodeLdsLean, DecodeLds>::type;
+    __shared__ Lds S;
     extern __shared__ __align__(16) uint8_t rows_raw[];
     uint8_t *rows = rows_raw + 4;                                        // serial_engine.h row_stride: margins for the lane-parallel front
     const SerialJob &J = jobs[blockIdx.x];
@@ -1036,7 +1057,17 @@ __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restric
     const auto st_tab = gp(reinterpret_cast<uint32_t *>(J.state + 1));
     constexpr int kTabWords = int((kDecodeStateBytes - sizeof(SerialState)) / 4);
     uint32_t *lds_tab = reinterpret_cast<uint32_t *>(&S);
+    uint32_t *lds_sym = reinterpret_cast<uint32_t *>(&S.sym_at[0][0]);
     const int lane = int(threadIdx.x);
+    // the tables between the image's state record and LDS (the lean image: contexts and counters, then the rank -> symbol table)
+    auto tables = [&](auto move) {
+        if constexpr (LEAN) {
+            for (int k = lane; k < kRecCount; k += 64) move(lds_tab[k], st_tab[k]);
+            for (int k = lane; k < 512 * kMapSyms / 4; k += 64) move(lds_sym[k], st_tab[kRecSym + k]);
+        } else {
+            for (int k = lane; k < kTabWords; k += 64) move(lds_tab[k], st_tab[k]);
+        }
+    };
     if (st->status != kRunning) return;                                  // finished, failed, or waiting for the host to feed the stream
     const int i0 = st->next_row, i1 = i0 + J.rows < J.h ? i0 + J.rows : J.h;
     const bool final_ = st->final_ != 0;
@@ -1050,10 +1081,13 @@ __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restric
         for (int k = lane; k < kLevels * kTreeNodes; k += 64) (&S.cnt[0][0])[k] = uint32_t(kWeightOne) | (uint32_t(kWeightOne) << 16);
         for (int k = lane; k < 512 * kMapSyms; k += 64) {
             const int s = k % kMapSyms;
-            (&S.count[0][0])[k] = 2 * (kMapSyms - 1 - s); (&S.rank_of[0][0])[k] = uint8_t(s); (&S.sym_at[0][0])[k] = uint8_t(s);
+            (&S.sym_at[0][0])[k] = uint8_t(s);
+            if constexpr (LEAN) st_tab[kRecCount + k] = uint32_t(2 * (kMapSyms - 1 - s));
+            else { (&S.count[0][0])[k] = 2 * (kMapSyms - 1 - s); (&S.rank_of[0][0])[k] = uint8_t(s); }
         }
+        if constexpr (LEAN) __threadfence_block();
     } else {
-        for (int k = lane; k < kTabWords; k += 64) lds_tab[k] = st_tab[k];
+        tables([](uint32_t &lds, NB_GLOBAL uint32_t &rec) { lds = rec; });
     }
     fill_qlut(S.qlut);
     if (lane < 16) S.q.vn8[lane] = 0;
@@ -1076,7 +1110,7 @@ __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restric
     else at = decode_body<N, false>(S, rows, J, rs, i0, i1, sw, cs, bias, final_, stop);
     wave_sync();
     if (stop == kFailed || stop == kStarvedMidRow) { if (lane == 0) st->status = stop; return; }
-    if (at < J.h) for (int k = lane; k < kTabWords; k += 64) st_tab[k] = lds_tab[k];
+    if (at < J.h) tables([](uint32_t &lds, NB_GLOBAL uint32_t &rec) { rec = lds; });
     if (lane == 0) {
         st->next_row = at; st->pos = sw.pos; st->lo = cs[0]; st->hi = cs[1]; st->window = cs[2]; st->bias = bias;
         st->status = at >= J.h ? kDone : stop;                           // kRunning (more rows to go) or kStarved (feed me)
@@ -1273,9 +1307,18 @@ __global__ void __launch_bounds__(64) k_serial_qdecode(const SerialJob *__restri
         const uint32_t s0 = gp(J.q_start)[k], f = gp(J.q_freq)[k];
         S.ctx[k] = i0 ? st_ctx[k] : 0;
         S.span[k] = (s0 & 0xFFFFu) | (((s0 + f) & 0xFFFFu) << 16);
-        (&S.coarse[0][0])[k] = gp(J.q_slot)[size_t(k >> 8) * 32768 + size_t(k & 255) * 128];
     }
     if (lane < 2) S.span[3072 + lane] = 0;
+    wave_sync();
+    for (int k = lane; k < 3072; k += 64) {                              // the symbol that holds slot 128 (k & 255) of level k >> 8: the last one starting at or below it
+        const uint32_t slot = uint32_t(k & 255) * 128u, *sp = S.span + (k & ~255);
+        int lo = 0, hi = 255;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((sp[mid] & 0xFFFFu) <= slot) lo = mid; else hi = mid - 1;
+        }
+        (&S.coarse[0][0])[k] = uint8_t(lo);
+    }
     wave_sync();
     // a row in LDS: two columns of margin on the left (after the four bytes in front of row 0, which hold zero for the
     // lanes without an operand) and at least four on the right -- the lane-parallel model reads the clamped columns there
@@ -1360,6 +1403,7 @@ int serial_selftest(hipStream_t s) {
 
 // ---- launchers ----------------------------------------------------------------------------------
 constexpr int kLdsBudget = 160 * 1024;
+constexpr int kLeanImages = 256;                  // decode launches of more images than this keep the hit counts in memory (four waves per CU)
 constexpr int kTwoWaveImages = 64;               // effort-3 launches of at most this many images give every image a second wave
 constexpr int lds_room(size_t static_lds) { return int(kLdsBudget - static_lds - 256) & ~15; }
 
@@ -1393,12 +1437,22 @@ bool serial_model_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n
     }
 }
 
-bool serial_decode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s) {
+bool serial_decode_launch(const SerialJob *d_jobs, const SerialJob *h_jobs, int n, hipStream_t s, bool whole_streams) {
     if (n <= 0) return true;
+    // More images than CUs: the lean LDS image (four waves per CU instead of one; a pixel pays two reads of its hit counts
+    // in L2 instead of LDS).  Only for streams that are there in full: a launch that runs dry inside a row is REDONE from
+    // the state record, and the lean image has already changed the counts in it.
+    if (whole_streams && n > kLeanImages) {
+        switch (h_jobs[0].effort) {
+            case 1: return launch_rows(k_serial_decode<0, true>, sizeof(DecodeLdsLean), d_jobs, h_jobs, n, s, 64, kRowPad);
+            case 2: return launch_rows(k_serial_decode<6, true>, sizeof(DecodeLdsLean), d_jobs, h_jobs, n, s, 64, kRowPad);
+            default: return launch_rows(k_serial_decode<10, true>, sizeof(DecodeLdsLean), d_jobs, h_jobs, n, s, 64, kRowPad);
+        }
+    }
     switch (h_jobs[0].effort) {
-        case 1: return launch_rows(k_serial_decode<0>, sizeof(DecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
-        case 2: return launch_rows(k_serial_decode<6>, sizeof(DecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
-        default: return launch_rows(k_serial_decode<10>, sizeof(DecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
+        case 1: return launch_rows(k_serial_decode<0, false>, sizeof(DecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
+        case 2: return launch_rows(k_serial_decode<6, false>, sizeof(DecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
+        default: return launch_rows(k_serial_decode<10, false>, sizeof(DecodeLds), d_jobs, h_jobs, n, s, 64, kRowPad);
     }
 }
 

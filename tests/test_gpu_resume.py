@@ -202,3 +202,31 @@ def test_two_wave_effort3_launches_are_exact_and_repeatable(gpu_ctx, pkg, oracle
         assert got == want
     finally:
         ctx.close()
+
+
+def test_lean_decoder_many_images_side_by_side(gpu_ctx, pkg, oracle):
+    """Decode launches of more than 256 images use the lean LDS image (serial_engine.hip DecodeLdsLean: the re-mappers'
+    hit counts stay in the image's state record in memory, four waves per CU instead of one).  300 streams per effort,
+    lossless and near-lossless, in one piece and in launches of 5 rows (the counts survive in the record between
+    launches), against the oracle's reconstructions; then 256 of them (the full LDS image) give the same planes."""
+    n = 300
+    cases = []
+    for k in range(n):
+        h, w = 12 + (k % 7) * 3, 16 + (k % 5) * 9
+        im = inputs.syn1(h, w, k + 1) if k % 4 else inputs.make("noise", h, w)
+        cases.append((im, (0, 2, 0, 5)[k % 4]))
+    ctx = pkg.Context(device=0, n_slots=8, n_coders=2, n_groups=1, n_host_buffers=16)
+    try:
+        for effort in (1, 2, 3):
+            enc = [oracle.encode(im, near, effort) for im, near in cases]
+            streams = [e[0] for e in enc]
+            for rows in (0, 5):
+                ctx.set_serial_rows(rows)
+                dec = ctx.decode_batch(streams)
+                for (im, near), e, d in zip(cases, enc, dec):
+                    assert d is not None and np.array_equal(d[0], e[1]) and d[1:] == (near, effort), (effort, rows, im.shape, near)
+            ctx.set_serial_rows(0)
+            dec = ctx.decode_batch(streams[:256])
+            assert all(d is not None and np.array_equal(d[0], e[1]) for e, d in zip(enc, dec)), effort
+    finally:
+        ctx.close()
