@@ -917,6 +917,89 @@ struct StreamWindow {
     }
 };
 
+// One symbol of the NBLIC decoder (NBLIC.c:640-679, :628-637, :552-573) with the PROBABILITIES on the lanes.  A symbol's
+// bins are a unary prefix over the nodes 0, S, 2S, ... (S = 1 << k_max) and then k suffix bits down a binary tree below
+// the node the prefix stopped at.  Which bins are coded depends on the stream; which nodes CAN come does not, and a
+// symbol never visits a counter twice -- so lane t reads the counters of prefix node t and mixes their probability
+// while lane 0 ... all at once, the serial part of a bin shrinks to the coder's interval arithmetic (one v_readlane,
+// a 32 x 12-bit product, a compare, the renormalisation), and the counters of the bins that were coded are updated by
+// their lanes together.  The suffix likewise: lane l holds node l of the tree in heap order (2^k - 1 nodes, k <= 5).
+// Prefixes longer than the lanes (64 nodes, or the end of the tree: the reference moves on to the next level's tree)
+// continue bin by bin as the reference does.
+template <class Lds>
+__device__ __forceinline__ int decode_symbol(Lds &S, const Level &L, const int k_step, const uint64_t ktab, uint32_t &lo, uint32_t &hi,
+                                             uint32_t &window, StreamWindow &sw, bool &damaged, const int lane, const int sfx_d, const int sfx_prefix) {
+    const int k_max = int(ktab >> 60), qw = L.qw;
+    int qu = L.qu, qv = L.qv;
+    int k = int(ktab >> (4 * qu)) & 15;
+    if ((int(ktab >> (4 * qv)) & 15) != k) qv = qu;
+    auto prob_of = [&](uint32_t cu, uint32_t cv) {
+        return mix_prob(prob_one(int(cu & 0xFFFFu), int(cu >> 16)), prob_one(int(cv & 0xFFFFu), int(cv >> 16)), qw);
+    };
+    auto code = [&](int prob, bool stop) {                               // one bin off the stream (uniform)
+        const uint32_t cut = lo + uint32_t((u64(hi - lo) * uint32_t(prob)) >> 12);
+        const int bin = (sw.dry | stop) ? 0 : int(window <= cut);
+        if (bin) hi = cut; else lo = cut + 1;
+        while (((lo ^ hi) >> 24) == 0 && !sw.dry) { window = (window << 8) | sw.next(); lo <<= 8; hi = (hi << 8) | 0xFFu; }
+        return bin;
+    };
+    auto settle = [&](uint32_t cu, uint32_t cv, int node, int bin) {     // the bin into its two counters (one, if the levels coincide)
+        Counter a{int(cu & 0xFFFFu), int(cu >> 16)};
+        counter_add(a, bin, kWeightOne - qw);
+        if (qu == qv) counter_add(a, bin, qw);
+        S.cnt[qu][node] = uint32_t(a.c0) | (uint32_t(a.c1) << 16);
+        if (qu != qv) {
+            Counter b{int(cv & 0xFFFFu), int(cv >> 16)};
+            counter_add(b, bin, qw);
+            S.cnt[qv][node] = uint32_t(b.c0) | (uint32_t(b.c1) << 16);
+        }
+    };
+    // prefix
+    const int reach = (kTreeNodes >> k_max) < 64 ? (kTreeNodes >> k_max) : 64;
+    int node = lane < reach ? lane << k_max : 0;
+    uint32_t cu = S.cnt[qu][node], cv = S.cnt[qv][node];
+    int P = prob_of(cu, cv);
+    int t = 0, bin;
+    for (;;) {
+        bin = code(__builtin_amdgcn_readlane(P, t), false);
+        if (!bin || ++t == reach) break;
+    }
+    if (lane < t + 1 - bin) settle(cu, cv, node, int(lane < t));         // lanes 0 .. t-1 saw a one, lane t (if there) the zero
+    node = t << k_max;
+    if (bin) {                                                           // beyond the lanes
+        int bins = reach;
+        for (;;) {
+            if (node >= kTreeNodes) { node >>= 1; k++; qu = qv = k * k_step; }
+            cu = S.cnt[qu][node]; cv = S.cnt[qv][node];
+            // a symbol of a valid stream has well under a hundred bins; a damaged one (all ones) could walk for ever:
+            // from the 512th bin of a pixel on, and once the stream has run dry, every symbol ends at once
+            if (++bins > 512) damaged = true;
+            bin = code(prob_of(cu, cv), damaged);
+            settle(cu, cv, node, bin);
+            if (!bin) break;
+            node += 1 << k_max;
+        }
+    }
+    int z = (node >> k_max) << k;
+    if (k > 0) {                                                         // suffix: node + 1 is the root; a one at depth d moves on by 2^(k-d), a zero by 1
+        const int off = sfx_d - __popc(sfx_prefix) + (sfx_prefix << (k > sfx_d ? k - sfx_d : 0));
+        int n2 = node + 1 + (sfx_d < k ? off : 0);
+        n2 = n2 < kTreeNodes ? n2 : kTreeNodes - 1;
+        cu = S.cnt[qu][n2]; cv = S.cnt[qv][n2];
+        P = prob_of(cu, cv);
+        int at = 0;
+        u64 seen = 0, ones = 0;
+        for (int kk = k - 1; kk >= 0; kk--) {
+            bin = code(__builtin_amdgcn_readlane(P, at), damaged);
+            seen |= 1ull << at;
+            if (bin) { ones |= 1ull << at; z += 1 << kk; }
+            at = 2 * at + 1 + bin;
+        }
+        if ((seen >> lane) & 1ull) settle(cu, cv, n2, int((ones >> lane) & 1ull));
+    }
+    return z;
+}
+
 // rows [i0, i1) of the image; coder state in / out through `cs` (lo, hi, window); returns the row it stopped in front of
 // and sets `stop` to kRunning (ran its rows), kStarved, kStarvedMidRow or kFailed
 template <int N, bool CACHED, class Lds>
@@ -936,6 +1019,7 @@ __device__ __forceinline__ int decode_body(Lds &S, uint8_t *rows, const SerialJo
     if constexpr (N > 0) lw.init(J.stats, w, lane, 0, bias_io);
     LaneFront lf;
     lf.init(lane, &S.q);
+    const int sfx_d = 31 - __clz(lane + 1), sfx_prefix = lane + 1 - (1 << sfx_d);      // decode_symbol: the lane's place in the suffix tree
     uint32_t lo = cs[0], hi = cs[1], window = cs[2];
     if (CACHED && i0 > 0) {                                              // resuming: the two rows above come back from the decoded plane
         for (int r = i0 > 1 ? i0 - 2 : i0 - 1; r < i0; r++) {
@@ -977,30 +1061,7 @@ __device__ __forceinline__ int decode_body(Lds &S, uint8_t *rows, const SerialJo
             const int v = S.ctx[adr];
             const int sign = bias_sign(v), px = bias_apply(v, px0);
             const int mk = px * 2 + sign;
-            int bins_px = 0;
-            const int z = walk_symbol_t(k_step, ktab, L.qu, L.qv, -1, [&](int qu, int qv, int node, int) {       // NBLIC.c:628-637, :552-573
-                const uint32_t cu = S.cnt[qu][node], cv = S.cnt[qv][node];
-                const int u0 = int(cu & 0xFFFFu), u1 = int(cu >> 16);
-                const int v0 = int(cv & 0xFFFFu), v1 = int(cv >> 16);
-                const int prob = mix_prob(prob_one(u0, u1), prob_one(v0, v1), L.qw);
-                const uint32_t cut = lo + uint32_t((u64(hi - lo) * uint32_t(prob)) >> 12);
-                // a symbol of a valid stream has well under a hundred bins; a damaged one (all ones) could walk for ever:
-                // from the 512th bin of a pixel on, and once the stream has run dry, every symbol ends at once
-                if (++bins_px > 512) damaged = true;
-                const int bin = (sw.dry | damaged) ? 0 : int(window <= cut);
-                if (bin) hi = cut; else lo = cut + 1;
-                while (((lo ^ hi) >> 24) == 0 && !sw.dry) { window = (window << 8) | sw.next(); lo <<= 8; hi = (hi << 8) | 0xFFu; }
-                Counter a{u0, u1};
-                counter_add(a, bin, kWeightOne - L.qw);
-                if (qu == qv) counter_add(a, bin, L.qw);                 // same counter takes both weights
-                S.cnt[qu][node] = uint32_t(a.c0) | (uint32_t(a.c1) << 16);
-                if (qu != qv) {
-                    Counter b{v0, v1};
-                    counter_add(b, bin, L.qw);
-                    S.cnt[qv][node] = uint32_t(b.c0) | (uint32_t(b.c1) << 16);
-                }
-                return bin;
-            });
+            const int z = decode_symbol(S, L, k_step, ktab, lo, hi, window, sw, damaged, lane, sfx_d, sfx_prefix);
             if (sw.dry | damaged) return;                                // the image cannot be finished from here: no pixel is written for this symbol
             const int y = z < kMapSyms ? int(S.sym_at[mk][z]) : z;
             if (y < kMapSyms) {                                          // NBLIC.c:497-523 (z is y's rank)
