@@ -11,7 +11,7 @@ import numpy as np
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--batch", type=int, default=64)
-ap.add_argument("--modes", default="2:1,0:2,2:2,0:3")
+ap.add_argument("--modes", default="0:1,2:1,0:2,2:2,0:3")
 ap.add_argument("--groups", type=int, default=2, help="groups the images in flight are split into (each launches its own kernels on its own stream)")
 args = ap.parse_args()
 pkg = importlib.import_module("nblic-image-compression_amd")
