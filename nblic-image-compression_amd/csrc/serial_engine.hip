@@ -466,10 +466,10 @@ struct LsqWalk {
         const u64 okm = __ballot(ok != 0);
         ok1 = (okm & 1ull) != 0; ok2 = ((okm >> L::R) & 1ull) != 0;
         if (bad) {                                                       // magnitudes left the exact range: integers decide (rare)
-            i64 q1 = 0, q2 = 0;
-            ok1 = lsq_solve_int(S, N, b1, &q1) != 0;
-            ok2 = lsq_solve_int(S, N, b2, &q2) != 0;
-            p1 = clamp_q12(q1); p2 = clamp_q12(q2);
+            i64 q1 = 0, q2 = 0;                                          // (the results are the same on every lane: say so, or everything downstream is compiled as divergent)
+            ok1 = __builtin_amdgcn_readfirstlane(lsq_solve_int(S, N, b1, &q1)) != 0;
+            ok2 = __builtin_amdgcn_readfirstlane(lsq_solve_int(S, N, b2, &q2)) != 0;
+            p1 = __builtin_amdgcn_readfirstlane(clamp_q12(q1)); p2 = __builtin_amdgcn_readfirstlane(clamp_q12(q2));
         }
     }
     // WAVES = 2: this wave's ONE system.  The main wave keeps p1 / ok1 (and redoes its system with integers at once if
@@ -485,15 +485,16 @@ struct LsqWalk {
         const bool ok_mine = (__ballot(ok != 0) & 1ull) != 0;
         if (main) {
             p1 = mine; ok1 = ok_mine;
-            if (bad) { i64 q1 = 0; ok1 = lsq_solve_int(S, N, b1, &q1) != 0; p1 = clamp_q12(q1); }
+            if (bad) { i64 q1 = 0; ok1 = __builtin_amdgcn_readfirstlane(lsq_solve_int(S, N, b1, &q1)) != 0; p1 = __builtin_amdgcn_readfirstlane(clamp_q12(q1)); }
         } else {
             S.xch[0] = mine; S.xch[1] = int(ok_mine); S.xch[2] = int(bad);
         }
     }
     // WAVES = 2, main wave, after the barrier that follows solve_one: the other system's result
     __device__ __forceinline__ void take_other(LsqLds &S) {
-        p2 = S.xch[0]; ok2 = S.xch[1] != 0;
-        if (S.xch[2]) { i64 q2 = 0; ok2 = lsq_solve_int(S, N, b2, &q2) != 0; p2 = clamp_q12(q2); }
+        const int x0 = S.xch[0], x1 = S.xch[1], x2 = S.xch[2];           // one round trip for the three
+        p2 = __builtin_amdgcn_readfirstlane(x0); ok2 = __builtin_amdgcn_readfirstlane(x1) != 0;
+        if (__builtin_amdgcn_readfirstlane(x2)) { i64 q2 = 0; ok2 = __builtin_amdgcn_readfirstlane(lsq_solve_int(S, N, b2, &q2)) != 0; p2 = __builtin_amdgcn_readfirstlane(clamp_q12(q2)); }
     }
     // fold the coded pixel in (NBLIC.c:242-283, :882-893) and publish the next pixel's statistics
     __device__ __forceinline__ void update(LsqLds &S, int j, int xr, int p1_used) {
@@ -757,8 +758,12 @@ __device__ __forceinline__ void block_sync() { asm volatile("s_waitcnt lgkmcnt(0
 
 template <int N, bool CACHED, int WAVES>
 __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const SerialJob &J, const int rs, const int i0, const int i1, int &bias_io) {
-    const int w = J.w, lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+    // (the wave number is the same on every lane: read it as a scalar, or `main` and everything under it is compiled as divergent)
+    const int w = J.w, lane = int(threadIdx.x) & 63, wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(int(threadIdx.x)) >> 6;
     const bool main = wave == 0;
+    // One wave per image: what every lane has read alike is declared uniform, and the rest of the pixel compiles to scalar
+    // code (-3 % per pixel at effort 2).  With a second wave sharing the LDS the same change measured +1..2 %: left as it was.
+    auto uni = [](int v) { return WAVES == 1 ? __builtin_amdgcn_readfirstlane(v) : v; };
     const NearParams np = near_params(J.near);
     const auto img = gp(J.img);
     const auto recon = gp(J.recon);
@@ -797,7 +802,7 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
             int x = 0;
             if (main) {
                 front.begin(j);
-                x = CACHED ? x_next : int(img[row_at + j]);
+                x = uni(CACHED ? x_next : int(img[row_at + j]));
                 if (CACHED) x_next = r0[j + 1 < w ? j + 1 : j];            // the next original pixel: requested a pixel ahead
                 if constexpr (N > 0) front.regressors();
             }
@@ -815,9 +820,9 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
                     px0 = front.predict();
                 }
                 const int delta = front.activity(err);
-                const Level L = level_from(S.qlut[delta < 200 ? delta : 200]);
+                const Level L = level_from(uint16_t(uni(S.qlut[delta < 200 ? delta : 200])));
                 const int adr = front.context(L.qu, px0);
-                const int v = S.ctx[adr];
+                const int v = uni(S.ctx[adr]);                            // every lane reads the same word: the rest of the pixel is scalar code
                 const int sign = bias_sign(v), px = bias_apply(v, px0);
                 const int y = residual_to_symbol(x, px, sign, np);
                 xr = __builtin_amdgcn_readfirstlane(symbol_to_pixel(y, px, sign, np));
@@ -1056,14 +1061,14 @@ __device__ __forceinline__ int decode_body(Lds &S, uint8_t *rows, const SerialJo
                 px0 = front.predict();
             }
             const int delta = front.activity(err);
-            const Level L = level_from(S.qlut[delta < 200 ? delta : 200]);
+            const Level L = level_from(uint16_t(__builtin_amdgcn_readfirstlane(S.qlut[delta < 200 ? delta : 200])));
             const int adr = front.context(L.qu, px0);
-            const int v = S.ctx[adr];
+            const int v = __builtin_amdgcn_readfirstlane(S.ctx[adr]);
             const int sign = bias_sign(v), px = bias_apply(v, px0);
             const int mk = px * 2 + sign;
             const int z = decode_symbol(S, L, k_step, ktab, lo, hi, window, sw, damaged, lane, sfx_d, sfx_prefix);
             if (sw.dry | damaged) return;                                // the image cannot be finished from here: no pixel is written for this symbol
-            const int y = z < kMapSyms ? int(S.sym_at[mk][z]) : z;
+            const int y = z < kMapSyms ? __builtin_amdgcn_readfirstlane(int(S.sym_at[mk][z])) : z;
             if (y < kMapSyms) {                                          // NBLIC.c:497-523 (z is y's rank)
                 const int at = mk * kMapSyms + z;
                 const int c = hits[at] + 1;
