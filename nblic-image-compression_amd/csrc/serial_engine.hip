@@ -1311,7 +1311,7 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
                 const int lin = __builtin_amdgcn_readfirstlane(iclip(9 * (a + b) + 2 * (d - c) - e - f, 0, 16 * kMaxVal));
                 const int px0 = (8 * wt * ang + (8 - wt) * lin + 64) >> 7;
                 const int adr = (qd << 8) | int((__ballot((px0 << int(lc.sh)) > V) >> 36) & 0xFFull);
-                const int v = S.ctx[adr];
+                const int v_raw = S.ctx[adr];
                 // the symbol: nearly always one of the two just read
                 const uint32_t e0 = p0 >> 16, e1 = p1 >> 16;
                 int y;
@@ -1329,6 +1329,7 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
                 rans.x = mul_u24(rans.x >> 15, s1 - s0) + low - s0;               // < 2^17 times <= 2^15
                 if (rans.x < 65536u) { const uint32_t lo = sw.next(); rans.x = (rans.x << 16) | lo | (sw.next() << 8); }
                 // the pixel
+                const int v = __builtin_amdgcn_readfirstlane(v_raw);
                 const int sign = (v >> 10) & 1;
                 const int px = iclip(px0 + (v >> 11) + sign, 0, kMaxVal);
                 const int px_out = __builtin_amdgcn_readfirstlane(symbol_to_pixel(y, px, sign, 0));
