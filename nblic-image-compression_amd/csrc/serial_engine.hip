@@ -1275,19 +1275,27 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
             const uint8_t *pZ = lc.sel[2] == 0 ? zero : (lc.sel[2] == 1 ? r1 : r2) + lc.dx[2];
             const int stX = lc.sel[0] != 0, stY = lc.sel[1] != 0, stZ = lc.sel[2] != 0;
             int a = r1[0], e = a;                                         // the window hands on row i-1's first pixel
-            int X = *pX, Y = *pY, Z = *pZ;
-            for (int j = 0; j < w; j++) {
-                pX += stX; pY += stY; pZ += stZ;
-                const int Xn = *pX, Yn = *pY, Zn = *pZ;                              // the next pixel's operands
-                // everything that does not wait for the pixel on the left
-                const int s_yz = __mul24(e, int(lc.ce)) + (Y + Z);
-                const int x2 = X << 1;
+            // What of a pixel does not wait for the pixel on its left (whose value enters as `a` only) is computed one pixel
+            // AHEAD, in the shadow of the previous pixel's context and symbol lookups: the a-free part of every term, the
+            // rows-above part of the seven extrapolations and of the linear predictor.
+            struct Early { int s_yz, x2, ang_bcd, lin_part; };
+            auto early = [&](int X, int Y, int Z, int e_) {
+                Early E;
+                E.s_yz = __mul24(e_, int(lc.ce)) + (Y + Z);
+                E.x2 = X << 1;
                 const int b = __builtin_amdgcn_readlane(X, 2), c = __builtin_amdgcn_readlane(X, 1), d = __builtin_amdgcn_readlane(X, 3);
                 const int f = __builtin_amdgcn_readlane(Y, 6);
-                const int ang_bcd = __mul24(b, int(lc.cb)) + __mul24(c, int(lc.cc)) + __mul24(d, int(lc.cd));
+                E.ang_bcd = __mul24(b, int(lc.cb)) + __mul24(c, int(lc.cc)) + __mul24(d, int(lc.cd));
+                E.lin_part = 9 * b + 2 * (d - c) - e_ - f;
+                return E;
+            };
+            Early E = early(int(*pX), int(*pY), int(*pZ), e);
+            pX += stX; pY += stY; pZ += stZ;
+            int Xn = *pX, Yn = *pY, Zn = *pZ;                                         // pixel 1's operands
+            for (int j = 0; j < w; j++) {
                 // the lane's term
-                const int X2 = x2 + __mul24(a, int(lc.a2));
-                const int V = X2 - s_yz;
+                const int X2 = E.x2 + __mul24(a, int(lc.a2));
+                const int V = X2 - E.s_yz;
                 int Q = V < 0 ? -V : V;
                 Q += dpp_i32<kQuadX1>(Q); Q += dpp_i32<kQuadX2>(Q);                   // the quad's four terms
                 // level -> first lookup of the symbol search (its round trips to LDS run under the prediction)
@@ -1307,11 +1315,15 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
                 const uint32_t p0 = S.span[qd * 256 + yc], p1 = S.span[qd * 256 + yc + 1];
                 // prediction, second half
                 const int wt = __builtin_popcountll(__ballot(int(lc.thr_weight) <= spread));
-                const int ang = __builtin_amdgcn_readlane(ang_bcd + __mul24(a, int(lc.ca)), dir);
-                const int lin = __builtin_amdgcn_readfirstlane(iclip(9 * (a + b) + 2 * (d - c) - e - f, 0, 16 * kMaxVal));
+                const int ang = __builtin_amdgcn_readlane(E.ang_bcd + __mul24(a, int(lc.ca)), dir);
+                const int lin = iclip(E.lin_part + 9 * a, 0, 16 * kMaxVal);
                 const int px0 = (8 * wt * ang + (8 - wt) * lin + 64) >> 7;
                 const int adr = (qd << 8) | int((__ballot((px0 << int(lc.sh)) > V) >> 36) & 0xFFull);
                 const int v_raw = S.ctx[adr];
+                // in the shadow of those lookups: the next pixel's early part (its e is this pixel's a), the operands after it
+                const Early En = early(Xn, Yn, Zn, a);
+                pX += stX; pY += stY; pZ += stZ;
+                const int Xnn = *pX, Ynn = *pY, Znn = *pZ;
                 // the symbol: nearly always one of the two just read
                 const uint32_t e0 = p0 >> 16, e1 = p1 >> 16;
                 int y;
@@ -1337,7 +1349,7 @@ __device__ __forceinline__ int qdecode_rows(QDecodeLds &S, uint8_t *rows, const 
                 S.ctx[adr] = (__mul24(v, 127) + err * 2048 + 63) >> 7;
                 r0[j] = uint8_t(px_out);
                 e = a; a = px_out;
-                X = Xn; Y = Yn; Z = Zn;
+                E = En; Xn = Xnn; Yn = Ynn; Zn = Znn;
                 if (sw.dry) break;
             }
         } else {
