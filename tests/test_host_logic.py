@@ -26,6 +26,8 @@ def harness():
     lib.hh_model_encode.restype = C.c_long
     lib.hh_model_encode.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_long, C.POINTER(C.c_long)]
     lib.hh_check_divide_free.restype = C.c_long
+    lib.hh_check_lane_front.restype = C.c_long
+    lib.hh_check_lane_front.argtypes = [C.c_int, C.c_int]
     return lib
 
 
@@ -43,6 +45,14 @@ def harness_encode(lib, pkg, img, near, effort):
 
 def test_divide_free_helpers_exhaustive(harness):
     assert harness.hh_check_divide_free() == 0
+
+
+@pytest.mark.parametrize("qnblic", [0, 1])
+def test_lane_table_reproduces_the_model(harness, qnblic):
+    """csrc/lane_table.h (one model term per lane: the serial kernels' pixel front) walked on the CPU over random,
+    extreme, smooth and flat planes of widths 1..64, rows >= 2: predictor, activity, level, context address and
+    regressors equal model.h's on the taps the reference's sampling rules deliver."""
+    assert harness.hh_check_lane_front(qnblic, 7) == 0
 
 
 @pytest.mark.parametrize("near,effort", [(0, 1), (0, 2), (0, 3), (2, 1), (2, 2), (3, 3), (9, 1), (1, 3)])
