@@ -322,6 +322,14 @@ NB_HD int walk_symbol_t(int k_step, uint64_t ktab, int qu, int qv, int z_in, Ste
     return z;
 }
 
+// The suffix bits of a symbol walk down a binary tree below the node the prefix stopped at: a one at depth d moves on
+// by 2^(k-1-d) nodes, a zero by one (walk_symbol's second loop).  The decoders hold that tree in heap order, one node
+// per lane (serial_engine.hip decode_symbol): lane l is the node at depth d = floor(log2(l + 1)) reached by the bits
+// prefix = l + 1 - 2^d (first bit in the most significant place), and its distance from the tree's root is
+NB_HD int suffix_lane_offset(int k, int d, int prefix) {
+    return d - __builtin_popcount(unsigned(prefix)) + (prefix << (k > d ? k - d : 0));
+}
+
 // ---- record packing shared by the staged -e1 kernels -------------------------------------
 // S1 record, one u32 per pixel:  px0[0:8) | adr[8:19) | qw[19:24) | qu_lsb[24] | qv_rel[25:27)
 // qv_rel: 0 -> qv == qu, 1 -> qv == qu + 1, 2 -> qv == qu - 1.  qu = ((adr >> 8) << 1) | qu_lsb.

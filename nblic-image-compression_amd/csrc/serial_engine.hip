@@ -933,7 +933,7 @@ __device__ __forceinline__ int decode_symbol(Lds &S, const Level &L, const int k
     }
     int z = (node >> k_max) << k;
     if (k > 0) {                                                         // suffix: node + 1 is the root; a one at depth d moves on by 2^(k-d), a zero by 1
-        const int off = sfx_d - __popc(sfx_prefix) + (sfx_prefix << (k > sfx_d ? k - sfx_d : 0));
+        const int off = suffix_lane_offset(k, sfx_d, sfx_prefix);
         int n2 = node + 1 + (sfx_d < k ? off : 0);
         n2 = n2 < kTreeNodes ? n2 : kTreeNodes - 1;
         cu = S.cnt[qu][n2]; cv = S.cnt[qv][n2];

@@ -316,3 +316,41 @@ extern "C" long hh_check_lane_front(int qnblic, int seed) {
     }
     return bad;
 }
+
+// The decoders' lane layout of a symbol's bins (serial_engine.hip decode_symbol) against the walk itself: for every
+// k_step, level pair and symbol, the nodes walk_symbol visits must be node t << k_max for the t-th prefix bin (while the
+// prefix stays inside the level's tree and the lanes: afterwards the kernel walks bin by bin like the reference) and, for
+// the suffix, root + suffix_lane_offset(k, d, prefix) with the lane moving 2 l + 1 + bin in heap order.
+extern "C" long hh_check_symbol_lanes(void) {
+    long bad = 0, checked = 0;
+    for (int near = 0; near <= kMaxNear; near++) {
+        const int k_step = k_step_for_near(near), k_max = (kLevels - 1) / k_step;
+        const int reach = (kTreeNodes >> k_max) < 64 ? (kTreeNodes >> k_max) : 64;
+        for (int qu = 0; qu < kLevels; qu++)
+            for (int dq = -1; dq <= 1; dq++) {
+                const int qv = qu + dq;
+                if (qv < 0 || qv >= kLevels) continue;
+                for (int z = 0; z < 400; z++) {
+                    std::vector<int> nodes, bins;
+                    walk_symbol(k_step, qu, qv, z, [&](int, int, int node, int bin) { nodes.push_back(node); bins.push_back(bin); return bin; });
+                    // prefix: bins up to and including the first zero
+                    size_t n_prefix = 0;
+                    while (bins[n_prefix]) n_prefix++;
+                    n_prefix++;
+                    for (size_t t = 0; t < n_prefix && int(t) < reach; t++) { bad += nodes[t] != int(t) << k_max; checked++; }
+                    // suffix: heap order below the node after the prefix's last
+                    const int k = int(nodes.size() - n_prefix), root = nodes[n_prefix - 1] + 1;
+                    int lane = 0;
+                    for (int s = 0; s < k; s++) {
+                        int d = 0;
+                        while ((2 << d) <= lane + 1) d++;
+                        const int prefix = lane + 1 - (1 << d);
+                        bad += d != s || lane >= 64 || nodes[n_prefix + s] != root + suffix_lane_offset(k, d, prefix);
+                        checked++;
+                        lane = 2 * lane + 1 + bins[n_prefix + s];
+                    }
+                }
+            }
+    }
+    return checked > 100000 ? bad : -1;
+}

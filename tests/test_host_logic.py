@@ -27,6 +27,7 @@ def harness():
     lib.hh_model_encode.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_long, C.POINTER(C.c_long)]
     lib.hh_check_divide_free.restype = C.c_long
     lib.hh_check_lane_front.restype = C.c_long
+    lib.hh_check_symbol_lanes.restype = C.c_long
     lib.hh_check_lane_front.argtypes = [C.c_int, C.c_int]
     return lib
 
@@ -45,6 +46,13 @@ def harness_encode(lib, pkg, img, near, effort):
 
 def test_divide_free_helpers_exhaustive(harness):
     assert harness.hh_check_divide_free() == 0
+
+
+def test_symbol_bins_lane_layout_matches_the_walk(harness):
+    """The decoders compute a symbol's bin probabilities on the lanes (serial_engine.hip decode_symbol): prefix node t on
+    lane t, the suffix tree in heap order.  Every (k_step, level pair, symbol): the nodes the reference's walk visits are
+    the ones that layout names."""
+    assert harness.hh_check_symbol_lanes() == 0
 
 
 @pytest.mark.parametrize("qnblic", [0, 1])
