@@ -290,6 +290,15 @@ NB_HD int symbol_to_pixel(int y, int px, int sign, const NearParams &p) {
     return iclip(up ? px + mag : px - mag, 0, kMaxVal);
 }
 
+// What the decoder will reconstruct for pixel x predicted as px (NBLIC.c:431-466): symbol_to_pixel(residual_to_symbol(x))
+// without the symbol.  The quantised magnitude q survives the folding unchanged and the direction is x >= px in both of
+// its branches (beyond the fold limit only the side with room is left, which is where x lies); checked exhaustively
+// against the round trip in tests/host_harness.cpp.  sign does not matter.
+NB_HD int reconstruct_pixel(int x, int px, const NearParams &p) {
+    const int d = x - px, mag = div_width((d < 0 ? -d : d) + p.near, p) * p.width;
+    return iclip(d >= 0 ? px + mag : px - mag, 0, kMaxVal);
+}
+
 // level / k_step for the sixteen levels, four bits each (bits 60..63 = 15 / k_step = k_max)
 NB_HD uint64_t level_shift_table(int k_step) {
     uint64_t t = 0;

@@ -768,10 +768,9 @@ __device__ __forceinline__ void model_body(ModelLds &S, uint8_t *rows, const Ser
                 const int adr = front.context(L.qu, px0);
                 const int v = uni(S.ctx[adr]);                            // every lane reads the same word: the rest of the pixel is scalar code
                 const int sign = bias_sign(v), px = bias_apply(v, px0);
-                // lossless: the pixel is reconstructed exactly (NBLIC.c:431-466 with near = 0), and the symbol itself is not
-                // this kernel's business (the entropy stages recompute it from the image and px | sign)
-                if (np.near == 0) xr = x;
-                else xr = __builtin_amdgcn_readfirstlane(symbol_to_pixel(residual_to_symbol(x, px, sign, np), px, sign, np));
+                // what the decoder will reconstruct, without the symbol (model.h reconstruct_pixel; the entropy stages recompute
+                // the symbol from the image and px | sign): lossless it is the pixel itself
+                xr = np.near == 0 ? x : __builtin_amdgcn_readfirstlane(reconstruct_pixel(x, px, np));
                 err = clip_err(xr, px0);
                 S.ctx[adr] = bias_update(v, err);
                 if (CACHED) r0[j] = uint8_t(xr); else { recon[row_at + j] = uint8_t(xr); __threadfence_block(); }

@@ -213,6 +213,7 @@ extern "C" long hh_check_divide_free(void) {
             for (int sign = 0; sign < 2; sign++) {
                 for (int x = 0; x < 256; x++) bad += residual_to_symbol(x, px, sign, np) != residual_to_symbol(x, px, sign, near);
                 for (int y = 0; y < 300; y++) bad += symbol_to_pixel(y, px, sign, np) != symbol_to_pixel(y, px, sign, near);
+                for (int x = 0; x < 256; x++) bad += reconstruct_pixel(x, px, np) != symbol_to_pixel(residual_to_symbol(x, px, sign, near), px, sign, near);
             }
         const int k_step = k_step_for_near(near);
         const uint64_t ktab = level_shift_table(k_step);
