@@ -2,9 +2,11 @@
 //
 // A lone wave issues one instruction every ~4 cycles and pays ~50 cycles for every dependent LDS
 // round trip, so these kernels are written for INSTRUCTION COUNT on the chain:
-//   * the scalar part of a pixel (taps, predictor, level, context, residual) is computed by all 64
-//     lanes alike (LDS reads broadcast, every lane stores the same value), with every integer divide
+//   * the model of a pixel (taps, predictor, activity, context comparisons, regressors) is spread over
+//     the lanes, one term each (lane_table.h, LaneFront); what is left of the scalar part runs as
+//     scalar code (values every lane read alike are declared uniform), with every integer divide
 //     replaced by a table or a reciprocal multiply (model.h NearParams / level_shift_table);
+//   * the decoders compute a symbol's bin probabilities on the lanes too (decode_symbol);
 //   * the least-squares predictor of efforts 2/3 (NBLIC.c:112-283) keeps its statistics in doubles
 //     that hold the reference's integers exactly (lsq_f64.h).  The two regularised systems of a
 //     pixel are solved side by side: lane r of the 16-lane row g holds row r of system g in
@@ -1128,13 +1130,13 @@ __global__ void __launch_bounds__(64) k_serial_decode(const SerialJob *__restric
     }
 }
 
-// ---- QNBLIC decoder (QNBLIC.c:493-555): one image per wave, every lane computing the same pixel -------
-// Context table, the twelve frequency / cumulative tables (16-bit: the histograms are normalised to 2^15)
-// and a coarse symbol index live in LDS: a symbol is found from the rANS state's low 15 bits by one coarse
-// lookup (the symbol of slot low & ~127) plus a short walk along the cumulative table, instead of a read
-// of the 384 KB slot table in memory on the pixel's critical path.  Taps: rows >= 2 use the sliding window
-// (QNBLIC's window neighbourhood equals direct sampling there except a / e at the row start);
-// rows 0 and 1 use the closed form of model.h sample_taps_q.
+// ---- QNBLIC decoder (QNBLIC.c:493-555): one image per wave ----------------------------------------------
+// Context table, the twelve cumulative tables (16-bit: the histograms are normalised to 2^15) and a coarse
+// symbol index -- built by the kernel itself from the cumulative table -- live in LDS: a symbol is found from the
+// rANS state's low 15 bits by one coarse lookup (the symbol of slot low & ~127) plus a short walk along the
+// cumulative table; no slot -> symbol table exists anywhere.  Rows >= 2 (rows that fit in LDS): the pixel's model
+// on the lanes (lane_table.h; QNBLIC's window neighbourhood equals clamped sampling there except a / e at the row
+// start); rows 0 and 1 use the closed form of model.h sample_taps_q on every lane alike.
 // Resumable like the others; a pixel consumes at most one 16-bit word, so a row never needs more than 2 w bytes
 // and a stream that is still being fed is only ever left in front of a row (kStarved).
 struct QDecodeLds {
