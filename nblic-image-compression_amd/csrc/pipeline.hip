@@ -283,7 +283,7 @@ struct nblic_amd_ctx {
     int dev_min_outstanding = 0;          // a pack is taken only while at least this many images of the submitted batches are unfinished
     double dev_bins = 0; long dev_packs = 0, dev_images = 0;
     // decode batches (nblic_amd_decode_batch): a stream of their own and grow-only device / pinned arenas
-    hipStream_t dec_stream = nullptr;
+    hipStream_t dec_stream = nullptr, dec_stream2 = nullptr;           // decode_batch alternates its chunks between the two
     uint8_t *dec_arena = nullptr; size_t dec_arena_cap = 0;
     SerialJob *dec_jobs = nullptr; int dec_jobs_cap = 0;
     int serial_rows = 0;                  // rows per launch of the serial kernels; 0 = sized for a few seconds per launch (nblic_amd_set_serial_rows)
@@ -1219,6 +1219,7 @@ long q_decode_tables(const uint16_t *in, size_t n_words, int *h, int *w, uint32_
 
 struct DecodeItem { int k, h, w, near, k_step, effort, kind; size_t len; long q_pos; int qtab; };      // kind 0 NBLIC, 1 QNBLIC; q_pos: first rANS word; qtab: which parsed table set
 
+constexpr int kDecodeChunk = 1024;                                                         // images per chunk of decode_batch (above the lean decoder's threshold)
 constexpr size_t kQTab = 2 * 12 * 256 * sizeof(uint32_t);                                   // QNBLIC: frequencies, cumulative starts (the kernel derives its symbol index from them)
 static size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
 
@@ -1290,52 +1291,83 @@ static bool decode_batch(nblic_amd_ctx *c, int n, const unsigned char *const *st
     std::stable_sort(items.begin(), items.end(), [](const DecodeItem &a, const DecodeItem &b) { return a.kind * 4 + a.effort < b.kind * 4 + b.effort; });
     const int m = int(items.size());
     if (!ensure_decode_space(c, arena, m)) return false;
-    hipStream_t st = c->dec_stream;
     std::vector<SerialJob> jobs(static_cast<size_t>(m));
     std::vector<SerialState> heads(static_cast<size_t>(m));
+    std::vector<uint8_t *> d_streams(static_cast<size_t>(m)), d_tabs(static_cast<size_t>(m), nullptr);
     size_t off = 0;
-    for (int i = 0; i < m; i++) {
+    for (int i = 0; i < m; i++) {                                        // the arena's layout
         const DecodeItem &it = items[size_t(i)];
         SerialJob &J = jobs[size_t(i)];
         J = SerialJob{};
-        uint8_t *d_stream = c->dec_arena + off; off += up256(it.len + 2048);
+        d_streams[size_t(i)] = c->dec_arena + off; off += up256(it.len + 2048);
         J.recon = c->dec_arena + off; off += up256(size_t(it.h) * size_t(it.w));
         const size_t sb = stats_doubles(it.effort, it.w) * sizeof(double);
-        if (sb) { J.stats = reinterpret_cast<double *>(c->dec_arena + off); off += up256(sb); HIP_OK(hipMemsetAsync(J.stats, 0, sb, st)); }
+        if (sb) { J.stats = reinterpret_cast<double *>(c->dec_arena + off); off += up256(sb); }
         J.state = reinterpret_cast<SerialState *>(c->dec_arena + off); off += decode_state_bytes(it);
-        HIP_OK(hipMemsetAsync(d_stream + (it.len & ~size_t(3)), 0, 2048, st));                 // the window reads whole 512-byte blocks past the end
-        HIP_OK(hipMemcpyAsync(d_stream, streams[it.k], it.len, hipMemcpyHostToDevice, st));
-        J.stream = d_stream;
+        J.stream = d_streams[size_t(i)];
         J.h = it.h; J.w = it.w; J.near = it.near; J.k_step = it.k_step; J.effort = it.effort;
         J.rows = serial_rows_per_launch(it.h, it.w, it.kind ? 1 : it.effort, c->serial_rows);
         SerialState &H = heads[size_t(i)];
         H = SerialState{};
         H.pos = it.kind ? (unsigned long long)(it.q_pos) * 2ull : (unsigned long long)(kHeaderBytes);
         H.avail = it.len; H.final_ = 1;
-        HIP_OK(hipMemcpyAsync(J.state, &H, sizeof H, hipMemcpyHostToDevice, st));
         if (it.kind == 1) {
-            uint8_t *d_tab = c->dec_arena + off; off += up256(kQTab);
-            HIP_OK(hipMemcpyAsync(d_tab, qtabs[size_t(it.qtab)].data(), kQTab, hipMemcpyHostToDevice, st));
-            J.q_freq = reinterpret_cast<const uint32_t *>(d_tab); J.q_start = J.q_freq + 12 * 256; J.q_slot = nullptr;
+            d_tabs[size_t(i)] = c->dec_arena + off; off += up256(kQTab);
+            J.q_freq = reinterpret_cast<const uint32_t *>(d_tabs[size_t(i)]); J.q_start = J.q_freq + 12 * 256; J.q_slot = nullptr;
         }
     }
-    HIP_OK(hipMemcpyAsync(c->dec_jobs, jobs.data(), size_t(m) * sizeof(SerialJob), hipMemcpyHostToDevice, st));
+    // Chunks of one (codec, effort) class, at most kDecodeChunk images each, alternate between two streams: a chunk's uploads,
+    // its launches (`rows` rows of every image per launch) and its copies back are all on ITS stream, and the host issues
+    // upload + launches of chunk n before it waits for the planes of chunk n - 1 -- so one chunk computes while the other's
+    // bytes cross the bus (the caller's memory is pageable: those copies hold the host thread, not the other stream).
+    struct Chunk { int i0, i1; hipStream_t st; };
+    std::vector<Chunk> chunks;
     for (int i0 = 0; i0 < m;) {
         int i1 = i0 + 1;
-        while (i1 < m && items[size_t(i1)].kind == items[size_t(i0)].kind && items[size_t(i1)].effort == items[size_t(i0)].effort) i1++;
-        int launches = 1;
-        for (int i = i0; i < i1; i++) launches = std::max(launches, serial_launches(jobs[size_t(i)].h, jobs[size_t(i)].rows));
-        for (int l = 0; l < launches; l++)
-            if (!decode_launch(items[size_t(i0)], c->dec_jobs + i0, jobs.data() + i0, i1 - i0, st, true)) { fprintf(stderr, "[nblic_amd] decode launch failed\n"); hipStreamSynchronize(st); return false; }
-        c->serial_launch_count += launches;
+        while (i1 < m && i1 - i0 < kDecodeChunk && items[size_t(i1)].kind == items[size_t(i0)].kind && items[size_t(i1)].effort == items[size_t(i0)].effort) i1++;
+        chunks.push_back(Chunk{i0, i1, (chunks.size() & 1) ? c->dec_stream2 : c->dec_stream});
         i0 = i1;
     }
-    for (int i = 0; i < m; i++) {
-        const DecodeItem &it = items[size_t(i)];
-        HIP_OK(hipMemcpyAsync(&heads[size_t(i)], jobs[size_t(i)].state, sizeof(SerialState), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(imgs[it.k], jobs[size_t(i)].recon, size_t(it.h) * size_t(it.w), hipMemcpyDeviceToHost, st));
+    auto fail = [&](const char *what) {
+        fprintf(stderr, "[nblic_amd] decode: %s failed\n", what);
+        hipStreamSynchronize(c->dec_stream); hipStreamSynchronize(c->dec_stream2);
+        return false;
+    };
+    auto upload_and_launch = [&](const Chunk &ch) {
+        hipStream_t st = ch.st;
+        for (int i = ch.i0; i < ch.i1; i++) {
+            const DecodeItem &it = items[size_t(i)];
+            const SerialJob &J = jobs[size_t(i)];
+            const size_t sb = stats_doubles(it.effort, it.w) * sizeof(double);
+            if (sb && hipMemsetAsync(J.stats, 0, sb, st) != hipSuccess) return false;
+            if (hipMemsetAsync(d_streams[size_t(i)] + (it.len & ~size_t(3)), 0, 2048, st) != hipSuccess) return false;      // the window reads whole 512-byte blocks past the end
+            if (hipMemcpyAsync(d_streams[size_t(i)], streams[it.k], it.len, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+            if (hipMemcpyAsync(J.state, &heads[size_t(i)], sizeof(SerialState), hipMemcpyHostToDevice, st) != hipSuccess) return false;
+            if (it.kind == 1 && hipMemcpyAsync(d_tabs[size_t(i)], qtabs[size_t(it.qtab)].data(), kQTab, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        }
+        if (hipMemcpyAsync(c->dec_jobs + ch.i0, jobs.data() + ch.i0, size_t(ch.i1 - ch.i0) * sizeof(SerialJob), hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        int launches = 1;
+        for (int i = ch.i0; i < ch.i1; i++) launches = std::max(launches, serial_launches(jobs[size_t(i)].h, jobs[size_t(i)].rows));
+        for (int l = 0; l < launches; l++)
+            if (!decode_launch(items[size_t(ch.i0)], c->dec_jobs + ch.i0, jobs.data() + ch.i0, ch.i1 - ch.i0, st, true)) return false;
+        c->serial_launch_count += launches;
+        return true;
+    };
+    auto download = [&](const Chunk &ch) {
+        for (int i = ch.i0; i < ch.i1; i++) {
+            const DecodeItem &it = items[size_t(i)];
+            if (hipMemcpyAsync(&heads[size_t(i)], jobs[size_t(i)].state, sizeof(SerialState), hipMemcpyDeviceToHost, ch.st) != hipSuccess) return false;
+            if (hipMemcpyAsync(imgs[it.k], jobs[size_t(i)].recon, size_t(it.h) * size_t(it.w), hipMemcpyDeviceToHost, ch.st) != hipSuccess) return false;
+        }
+        return true;
+    };
+    for (size_t n = 0; n < chunks.size(); n++) {
+        if (n >= 2 && hipStreamSynchronize(chunks[n].st) != hipSuccess) return fail("a chunk");      // heads[] of chunk n - 2 have landed before its stream is reused (its H2D reads heads of chunk n)
+        if (!upload_and_launch(chunks[n])) return fail("a launch");
+        if (n >= 1 && !download(chunks[n - 1])) return fail("a copy");
     }
-    HIP_OK(hipStreamSynchronize(st));
+    if (!download(chunks.back())) return fail("a copy");
+    if (hipStreamSynchronize(c->dec_stream) != hipSuccess || hipStreamSynchronize(c->dec_stream2) != hipSuccess) return fail("the last chunk");
     for (int i = 0; i < m; i++) status[items[size_t(i)].k] = heads[size_t(i)].status == kDone ? 0 : -1;
     return true;
 }
@@ -1817,6 +1849,7 @@ nblic_amd_ctx *nblic_amd_create_ex(int device, int n_groups, int group_size, int
     c->cbufs.resize(size_t(n_host_buffers));
     for (int i = 0; i < n_host_buffers; i++) c->free_cbufs.push_back(i);
     if (hipStreamCreateWithFlags(&c->dec_stream, hipStreamNonBlocking) != hipSuccess) { c->dec_stream = nullptr; nblic_amd_destroy(c); return nullptr; }
+    if (hipStreamCreateWithFlags(&c->dec_stream2, hipStreamNonBlocking) != hipSuccess) { c->dec_stream2 = nullptr; nblic_amd_destroy(c); return nullptr; }
     // (Measured and rejected: creating the copy streams with the highest stream priority, so that the
     // coder threads' short interleave kernels and copies overtake the encoder's long kernels -- the
     // pipeline drops from 4.9 to 3.1 Gpx/s.)
@@ -1864,6 +1897,7 @@ void nblic_amd_destroy(nblic_amd_ctx *c) {
     hipFree(c->dec_arena); hipFree(c->dec_jobs);
     if (c->feed_pipe[0] >= 0) { close(c->feed_pipe[0]); close(c->feed_pipe[1]); }
     if (c->dec_stream) hipStreamDestroy(c->dec_stream);
+    if (c->dec_stream2) hipStreamDestroy(c->dec_stream2);
     delete c;
 }
 
