@@ -157,6 +157,7 @@ struct DecodeLdsLean {
     uint32_t sbuf[256];
     LsqLds q;
 };
+static_assert(sizeof(DecodeLdsLean) <= 38 * 1024, "four lean decoder images (+ their row rings) per 160 KB of LDS");
 constexpr int kRecCount = kContexts + kLevels * kTreeNodes;              // word offsets of the tables in the state record (after SerialState)
 constexpr int kRecRank = kRecCount + 512 * kMapSyms, kRecSym = kRecRank + 512 * kMapSyms / 4;
 
